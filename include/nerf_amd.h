@@ -1,0 +1,144 @@
+/*
+ * nerf_amd.h -- C ABI of libnerf_amd.so: the MI355X (gfx950) NeRF volume-rendering hot path.
+ *
+ * This is the drop-in boundary.  The reference (1501454486/NeRF) is pure Python over
+ * PyTorch, so there is no reference FFI to mirror; each entry point below replaces the
+ * reference function it cites (paths relative to the reference root) and is what a
+ * ctypes / cffi binding on the reference side binds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 data unless the name ends in
+ *     `_host`;  sizes are element counts;  `stream` is a hipStream_t (NULL = default stream);
+ *   - no entry point allocates, frees or synchronises; work is enqueued on `stream`;
+ *     scratch is passed in by the caller (nrf_render_workspace_bytes);
+ *   - return value: 0 on success, a negative nrf_status otherwise (nrf_strerror gives text);
+ *     shapes are validated on the host before any launch;
+ *   - thread-safe for distinct streams / buffers; there is no hidden global state.
+ */
+#ifndef NERF_AMD_H
+#define NERF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nrf_stream_t; /* hipStream_t */
+
+typedef enum nrf_status {
+    NRF_OK = 0,
+    NRF_ERR_NULL = -1,       /* a required pointer is NULL */
+    NRF_ERR_SHAPE = -2,      /* a size is outside what the kernels support */
+    NRF_ERR_LAUNCH = -3,     /* hipGetLastError() reported a launch failure */
+    NRF_ERR_WORKSPACE = -4,  /* workspace too small */
+    NRF_ERR_ALIGN = -5       /* a pointer is not 16-byte aligned */
+} nrf_status;
+
+/* Layer order used by every `w[12]` / `b[12]` argument: the reference's state-dict layout
+ * (src/models/nerf/network.py:22-47): 0..7 pts_linears.{0..7}, 8 feature_linear,
+ * 9 alpha_linear, 10 views_linears.0, 11 rgb_linear; weights are nn.Linear (out, in)
+ * row-major fp32, biases (out,). */
+enum { NRF_NUM_LAYERS = 12 };
+
+int nrf_version(void);
+const char* nrf_strerror(int status);
+
+/* ---- weights ------------------------------------------------------------------------ */
+
+/* Number of floats of one model's weights in the MFMA streaming layout (incl. padding). */
+int64_t nrf_packed_floats(void);
+
+/* Permute one 8x256 NeRF MLP (network.py:9-47: 63->256, 4x 256->256, 319->256, 2x 256->256,
+ * feature 256->256, alpha 256->1, views 283->128, rgb 128->3) from the state-dict layout
+ * into the layout nrf_mlp_forward_* stream: per layer, per 32-row output block, per 32-wide
+ * K block, 1 KiB pieces ordered exactly as one wavefront's v_mfma_f32_32x32x2_f32 A-operands
+ * are consumed.  `w_host` / `b_host` are HOST arrays of 12 DEVICE pointers. */
+int nrf_pack_weights(const float* const* w_host, const float* const* b_host, float* packed,
+                     nrf_stream_t stream);
+
+/* ---- ray generation: src/datasets/nerf/blender.py:76-101 ---------------------------- */
+
+/* Rays [first_ray, first_ray + n_rays) of the row-major H x W pixel grid (or, when
+ * `pixel_index` is non-NULL, of the listed int64 flat pixel indices = the random-pixel draw
+ * of blender.py:82-85).  c2w_host: 12 doubles, rows of the 3x4 camera-to-world matrix.
+ * Math in fp64, results cast to fp32 like blender.py:99-100.  xyz, viewdirs: (n_rays, 3). */
+int nrf_raygen(const double* c2w_host, int H, int W, double focal, int64_t first_ray, int64_t n_rays,
+               const int64_t* pixel_index, float* xyz, float* viewdirs, nrf_stream_t stream);
+
+/* ---- stratified sampling: volume_renderer.py:209-220, 336-349 ----------------------- */
+
+/* add_perturbation: z_out[r,i] = lower + (upper - lower) * u[r,i] with mid-point bins of
+ * z_in.  z_in has `z_stride` floats between rays (0 = one shared table).  n <= 1024. */
+int nrf_perturb_samples(const float* z_in, int64_t z_stride, const float* u, int64_t n_rays, int n,
+                        float* z_out, nrf_stream_t stream);
+
+/* ---- the 8x256 MLP with fused point construction + positional encoding -------------- */
+
+/* volume_renderer.py:227-231 + _run_network :393-423 + Network.forward network.py:171-195 +
+ * freq.py:31-32 + NeRF.forward network.py:49-74, in one kernel.  For ray r, sample s:
+ * pts = rays_o[r] + z[r*z_stride + s] * (rays_d[r] / |rays_d[r]|); raw[r,s,:] = [r,g,b,sigma]
+ * (no activation).  n_samples must be a multiple of 32.  raw: (n_rays, n_samples, 4). */
+int nrf_mlp_forward_rays(const float* packed, const float* rays_o, const float* rays_d, const float* z,
+                         int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream);
+
+/* Network.forward on a flat batch (network.py:184-186): pts (n,3), dirs (n,3) used as given
+ * (not normalised).  raw: (n, 4). */
+int nrf_mlp_forward_points(const float* packed, const float* pts, const float* dirs, int64_t n_points,
+                           float* raw, nrf_stream_t stream);
+
+/* ---- alpha compositing: volume_renderer.py:222-224, 236-265 / 291-334 --------------- */
+
+/* sigma = relu(raw[...,3]); rgb = sigmoid(raw[...,:3]); delta = diff(z), last = 1e10;
+ * alpha = 1 - exp(-sigma*delta); T = exclusive cumprod(1 - alpha); w = T*alpha;
+ * rgb_map = sum w*rgb (+ 1 - acc if white_bkgd); depth = sum w*z; acc = sum w.
+ * One wavefront per ray, 64 samples per step, wave-wide product scan.
+ * n_samples multiple of 64, <= 1024.  weights (n_rays, n_samples) may be NULL. */
+int nrf_composite(const float* raw, const float* z, int64_t z_stride, int64_t n_rays, int n_samples,
+                  int white_bkgd, float* rgb_map, float* depth_map, float* acc_map, float* weights,
+                  nrf_stream_t stream);
+
+/* ---- importance resampling + merge: volume_renderer.py:363-391, 283-289 ------------- */
+
+/* pdf = w/(sum(w)+1e-10); cdf = [0, cumsum(pdf)]; idx = clamp(searchsorted(cdf, u, right) - 1,
+ * 0, 63); fine = bins[idx] + (bins[min(idx+1,63)] - bins[idx]) * u2; optional
+ * add_perturbation with u_fine; z_out = sort(cat(z_coarse, fine)).  Bit-exact with the
+ * reference on torch-CPU (8x4-lane fp32 sum, double running cumsum, no FMA contraction).
+ * n_coarse must be 64; n_importance a multiple of 64 with n_coarse + n_importance <= 256.
+ * bins / z_coarse: stride 0 = one shared 64-entry table.  fine_out (n_rays, n_importance)
+ * and idx_out (int32) may be NULL. */
+int nrf_sample_fine(const float* weights, const float* bins, int64_t bins_stride, const float* z_coarse,
+                    int64_t zc_stride, const float* u, const float* u2, const float* u_fine, int64_t n_rays,
+                    int n_coarse, int n_importance, float* z_out, float* fine_out, int32_t* idx_out,
+                    nrf_stream_t stream);
+
+/* ---- whole forward path: volume_renderer.py:143-153 (render_coarse + render_fine) --- */
+
+typedef struct nrf_render_args {
+    const float* packed_coarse;  /* nrf_pack_weights of Network.model      */
+    const float* packed_fine;    /* nrf_pack_weights of Network.model_fine */
+    const float* rays_o;         /* (n_rays, 3) batch['xyz']                */
+    const float* rays_d;         /* (n_rays, 3) batch['viewdirs'], un-normalised */
+    const float* bins;           /* (n_coarse,) near/far table (self.t_bins) */
+    const float* u;              /* (n_rays, n_importance) first torch.rand of importance_sampling */
+    const float* u2;             /* (n_rays, n_importance) second one */
+    const float* u_coarse;       /* (n_rays, n_coarse) or NULL: perturb>0 and is_training */
+    const float* u_fine;         /* (n_rays, n_importance) or NULL */
+    int64_t n_rays;
+    int n_coarse, n_importance, white_bkgd;
+    float* coarse_rgb;           /* (n_rays, 3) */
+    float* coarse_depth;         /* (n_rays,)   */
+    float* fine_rgb;             /* (n_rays, 3) */
+    float* fine_depth;           /* (n_rays,)   */
+    float* fine_acc;             /* (n_rays, 1) 'alpha_map' */
+    void* workspace;             /* >= nrf_render_workspace_bytes(...) */
+    int64_t workspace_bytes;
+} nrf_render_args;
+
+int64_t nrf_render_workspace_bytes(int64_t n_rays, int n_coarse, int n_importance);
+int nrf_render(const nrf_render_args* args, nrf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_AMD_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libnerf_amd.so (the C ABI declared in include/nerf_amd.h).
+
+There is no fallback: if the HIP library is missing or fails to load, importing the
+renderer raises.  Build it with ``make -C nerf_amd/csrc`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnerf_amd.so")
+
+# every symbol include/nerf_amd.h declares (tests/test_cabi_symbols.py checks the two agree)
+SYMBOLS = (
+    "nrf_version", "nrf_strerror", "nrf_packed_floats", "nrf_pack_weights", "nrf_raygen",
+    "nrf_perturb_samples", "nrf_mlp_forward_rays", "nrf_mlp_forward_points", "nrf_composite",
+    "nrf_sample_fine", "nrf_render_workspace_bytes", "nrf_render",
+)
+
+P = C.c_void_p
+I64 = C.c_int64
+INT = C.c_int
+
+
+class RenderArgs(C.Structure):
+    """struct nrf_render_args (include/nerf_amd.h)."""
+    _fields_ = [
+        ("packed_coarse", P), ("packed_fine", P), ("rays_o", P), ("rays_d", P), ("bins", P),
+        ("u", P), ("u2", P), ("u_coarse", P), ("u_fine", P),
+        ("n_rays", I64), ("n_coarse", INT), ("n_importance", INT), ("white_bkgd", INT),
+        ("coarse_rgb", P), ("coarse_depth", P), ("fine_rgb", P), ("fine_depth", P), ("fine_acc", P),
+        ("workspace", P), ("workspace_bytes", I64),
+    ]
+
+
+class NrfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NrfError(f"{LIB_PATH} not built: run `make -C nerf_amd/csrc` (hipcc --offload-arch=gfx950); "
+                       "there is no CPU/PyTorch fallback for the render path")
+    L = C.CDLL(LIB_PATH)
+    L.nrf_version.restype = INT
+    L.nrf_strerror.restype = C.c_char_p
+    L.nrf_strerror.argtypes = [INT]
+    L.nrf_packed_floats.restype = I64
+    L.nrf_pack_weights.argtypes = [P, P, P, P]
+    L.nrf_raygen.argtypes = [P, INT, INT, C.c_double, I64, I64, P, P, P, P]
+    L.nrf_perturb_samples.argtypes = [P, I64, P, I64, INT, P, P]
+    L.nrf_mlp_forward_rays.argtypes = [P, P, P, P, I64, I64, INT, P, P]
+    L.nrf_mlp_forward_points.argtypes = [P, P, P, I64, P, P]
+    L.nrf_composite.argtypes = [P, P, I64, I64, INT, INT, P, P, P, P, P]
+    L.nrf_sample_fine.argtypes = [P, P, I64, P, I64, P, P, P, I64, INT, INT, P, P, P, P]
+    L.nrf_render_workspace_bytes.restype = I64
+    L.nrf_render_workspace_bytes.argtypes = [I64, INT, INT]
+    L.nrf_render.argtypes = [C.POINTER(RenderArgs), P]
+    for name in ("nrf_pack_weights", "nrf_raygen", "nrf_perturb_samples", "nrf_mlp_forward_rays",
+                 "nrf_mlp_forward_points", "nrf_composite", "nrf_sample_fine", "nrf_render"):
+        getattr(L, name).restype = INT
+    _lib = L
+    return L
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise NrfError(f"{what}: {lib().nrf_strerror(status).decode()} (status {status})")

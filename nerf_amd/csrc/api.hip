@@ -1,0 +1,84 @@
+// Library-level entry points: version / error text and the whole coarse+fine forward path
+// (the intended body of Renderer.forward, volume_renderer.py:143-153) as one enqueue sequence.
+#include "nrf_common.h"
+
+NRF_EXPORT int nrf_version(void) { return 100; }
+
+NRF_EXPORT const char* nrf_strerror(int status) {
+    switch (status) {
+        case NRF_OK: return "ok";
+        case NRF_ERR_NULL: return "a required pointer is NULL";
+        case NRF_ERR_SHAPE: return "size outside the supported range (see include/nerf_amd.h)";
+        case NRF_ERR_LAUNCH: return "HIP kernel launch failed";
+        case NRF_ERR_WORKSPACE: return "workspace too small (see nrf_render_workspace_bytes)";
+        case NRF_ERR_ALIGN: return "pointer not 16-byte aligned";
+        default: return "unknown nrf_status";
+    }
+}
+
+namespace {
+
+inline int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
+
+struct Workspace {
+    int64_t raw, z_coarse, w_coarse, acc_coarse, z_fine, total;
+    Workspace(int64_t R, int nc, int ni) {
+        int64_t off = 0;
+        raw = off; off += align256(R * (nc + ni) * 4 * 4);   // raw (R, S, 4), sized for the fine pass
+        z_coarse = off; off += align256(R * nc * 4);         // only used when perturbed
+        w_coarse = off; off += align256(R * nc * 4);
+        acc_coarse = off; off += align256(R * 4);
+        z_fine = off; off += align256(R * (nc + ni) * 4);
+        total = off;
+    }
+};
+
+}  // namespace
+
+NRF_EXPORT int64_t nrf_render_workspace_bytes(int64_t n_rays, int n_coarse, int n_importance) {
+    if (n_rays < 0 || n_coarse <= 0 || n_importance <= 0) return NRF_ERR_SHAPE;
+    return Workspace(n_rays, n_coarse, n_importance).total;
+}
+
+NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) {
+    if (!a) return NRF_ERR_NULL;
+    if (!a->packed_coarse || !a->packed_fine || !a->rays_o || !a->rays_d || !a->bins || !a->u || !a->u2 ||
+        !a->coarse_rgb || !a->coarse_depth || !a->fine_rgb || !a->fine_depth || !a->fine_acc || !a->workspace)
+        return NRF_ERR_NULL;
+    if (a->n_rays < 0 || a->n_coarse != 64 || a->n_importance <= 0 || a->n_importance % 64 != 0 ||
+        a->n_coarse + a->n_importance > 256)
+        return NRF_ERR_SHAPE;
+    const Workspace ws(a->n_rays, a->n_coarse, a->n_importance);
+    if (a->workspace_bytes < ws.total) return NRF_ERR_WORKSPACE;
+    if (!nrf_aligned16(a->workspace)) return NRF_ERR_ALIGN;
+    if (a->n_rays == 0) return NRF_OK;
+    char* base = static_cast<char*>(a->workspace);
+    float* raw = reinterpret_cast<float*>(base + ws.raw);
+    float* zc_buf = reinterpret_cast<float*>(base + ws.z_coarse);
+    float* w_c = reinterpret_cast<float*>(base + ws.w_coarse);
+    float* acc_c = reinterpret_cast<float*>(base + ws.acc_coarse);
+    float* z_f = reinterpret_cast<float*>(base + ws.z_fine);
+    const int nc = a->n_coarse, ni = a->n_importance;
+    int st;
+    // render_coarse (volume_renderer.py:201-265)
+    const float* zc = a->bins;
+    int64_t zc_stride = 0;
+    if (a->u_coarse) {
+        if ((st = nrf_perturb_samples(a->bins, 0, a->u_coarse, a->n_rays, nc, zc_buf, stream))) return st;
+        zc = zc_buf;
+        zc_stride = nc;
+    }
+    if ((st = nrf_mlp_forward_rays(a->packed_coarse, a->rays_o, a->rays_d, zc, zc_stride, a->n_rays, nc, raw, stream)))
+        return st;
+    if ((st = nrf_composite(raw, zc, zc_stride, a->n_rays, nc, a->white_bkgd, a->coarse_rgb, a->coarse_depth, acc_c, w_c,
+                            stream)))
+        return st;
+    // render_fine (:267-334)
+    if ((st = nrf_sample_fine(w_c, a->bins, 0, zc, zc_stride, a->u, a->u2, a->u_fine, a->n_rays, nc, ni, z_f, nullptr,
+                              nullptr, stream)))
+        return st;
+    if ((st = nrf_mlp_forward_rays(a->packed_fine, a->rays_o, a->rays_d, z_f, nc + ni, a->n_rays, nc + ni, raw, stream)))
+        return st;
+    return nrf_composite(raw, z_f, nc + ni, a->n_rays, nc + ni, a->white_bkgd, a->fine_rgb, a->fine_depth, a->fine_acc,
+                         nullptr, stream);
+}

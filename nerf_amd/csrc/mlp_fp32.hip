@@ -1,0 +1,369 @@
+// Fused point construction + positional encoding + 8x256 NeRF MLP, fp32 on the CDNA4 matrix
+// cores (v_mfma_f32_32x32x2_f32), plus the weight packer that feeds it.
+//
+// Replaces (reference paths): volume_renderer.py:227-231 (normalise, pts = o + z*d),
+// :393-423 (_run_network chunk loop), network.py:171-195 (Network.forward, batchify),
+// encoding/freq.py:31-32 (sin/cos encoding), network.py:49-74 (NeRF.forward).
+//
+// Design (MI355X-first, not a translation):
+//   * Transposed GEMM chain  Y^T = W . X^T : the 32x32 MFMA's B operand is the activation
+//     (k = feature, column = point), the A operand is the weight matrix.  The accumulator
+//     layout of one layer (column = point on the lane, 16 rows in registers) is then exactly
+//     the B-operand layout of the next layer, so activations never leave the register file:
+//     no LDS, no barriers, no HBM round trips between the 10 GEMM layers.
+//   * One wavefront = 32 points x all 256 features: 128 accumulator registers in, 128 out
+//     (1 wave per SIMD, 512-register budget).
+//   * Weights are pre-permuted (nrf_pack_weights) into the order the wave consumes them, so
+//     the whole network is ONE linear 2.3 MiB stream of 1 KiB pieces per wavefront, read with
+//     global_load_dwordx4 through an 8-deep register ring (L2-resident: every wave streams
+//     the same bytes).  One float4 per lane feeds 4 MFMAs (256 matrix-core cycles).
+//   * PE (63 ch) and dir PE (27 ch) are computed in registers in the k-order the packed
+//     weights expect; alpha (256->1) and rgb (128->3) heads are VALU dot products.
+#include "nrf_common.h"
+
+using namespace nrf;
+
+// Kernel PE slot n of lane-half h -> column of the reference encoding
+// cat([x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]) (3 wide each), or -1.
+// Half 0 holds the sin terms, half 1 the cos terms; slots 3L, 3L+1 hold the raw input.
+__host__ __device__ static inline int pe_col(int n, int h, int L) {
+    if (n < 3 * L) return 3 + 6 * (n / 3) + 3 * h + (n % 3);
+    if (n == 3 * L) return h;               // x | y
+    if (n == 3 * L + 1) return h ? -1 : 2;  // z | pad
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------
+struct PackLayer {
+    const float* W;
+    float* dst;
+    int ldw, nob;
+    int pre_kb, hid_kb, post_kb;  // K blocks of 32: PE before / hidden / PE after
+    int pre_L, post_L;            // PE frequencies of the pre / post part
+    int pre_col0, hid_col0, post_col0;  // first source column of each part
+};
+
+__global__ void pack_layer_kernel(PackLayer p) {
+    const int nkb = p.pre_kb + p.hid_kb + p.post_kb;
+    const int total = p.nob * nkb * 4 * kStepFloats;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx & 3, lane = (idx >> 2) & 63, step = idx >> 8;
+    const int q = step & 3, kbpos = (step >> 2) % nkb, ob = (step >> 2) / nkb;
+    const int h = lane >> 5, t = 4 * q + e;
+    const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
+    float v = 0.f;
+    if (kbpos < p.pre_kb) {
+        const int c = pe_col(kbpos * 16 + t, h, p.pre_L);
+        if (c >= 0) v = p.W[row + p.pre_col0 + c];
+    } else if (kbpos < p.pre_kb + p.hid_kb) {
+        v = p.W[row + p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
+    } else {
+        const int c = pe_col((kbpos - p.pre_kb - p.hid_kb) * 16 + t, h, p.post_L);
+        if (c >= 0) v = p.W[row + p.post_col0 + c];
+    }
+    p.dst[idx] = v;
+}
+
+struct PackSmall {
+    const float* bias[10];  // pts0..7, feature, views
+    const float* alpha_w;
+    const float* alpha_b;
+    const float* rgb_w;
+    const float* rgb_b;
+    float* packed;
+};
+
+__global__ void pack_small_kernel(PackSmall p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float* dst = p.packed;
+    if (idx < kPrefetch * kStepFloats) dst[int64_t(kStreamSteps) * kStepFloats + idx] = 0.f;  // stream tail pad
+    if (idx >= kSmallFloats) return;
+    const int64_t o = kOffBias + idx;
+    if (o < kOffAlphaW) {  // [layer][ob][h][r]
+        const int layer = idx >> 8, r = idx & 15, h = (idx >> 4) & 1, ob = (idx >> 5) & 7;
+        dst[o] = p.bias[layer][ob * 32 + acc_row(r, h)];
+    } else if (o < kOffAlphaB) {  // alpha weights [kb][h][t]
+        const int i = int(o - kOffAlphaW), t = i & 15, h = (i >> 4) & 1, kb = i >> 5;
+        dst[o] = p.alpha_w[32 * kb + acc_row(t, h)];
+    } else if (o < kOffRgbW) {
+        dst[o] = o == kOffAlphaB ? p.alpha_b[0] : 0.f;
+    } else if (o < kOffRgbB) {  // rgb weights [c][kb][h][t]
+        const int i = int(o - kOffRgbW), t = i & 15, h = (i >> 4) & 1, kb = (i >> 5) & 3, c = i >> 7;
+        dst[o] = p.rgb_w[c * 128 + 32 * kb + acc_row(t, h)];
+    } else {
+        const int i = int(o - kOffRgbB);
+        dst[o] = i < 3 ? p.rgb_b[i] : 0.f;
+    }
+}
+
+NRF_EXPORT int64_t nrf_packed_floats(void) { return kPackedFloats; }
+
+NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, float* packed, nrf_stream_t stream_) {
+    if (!w || !b || !packed) return NRF_ERR_NULL;
+    for (int i = 0; i < NRF_NUM_LAYERS; ++i)
+        if (!w[i] || !b[i]) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    auto launch = [&](PackLayer p, int layer_slot) {
+        p.dst = packed + int64_t(kLayerStep[layer_slot]) * kStepFloats;
+        const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 4 * kStepFloats;
+        pack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+    };
+    // pts_linears.0: 63 PE -> 256
+    launch(PackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0}, 0);
+    for (int l = 1; l <= 7; ++l) {
+        if (l == 5)  // network.py:58 cat([input_pts, h]): PE columns first, then the 256 hidden
+            launch(PackLayer{w[5], nullptr, 319, 8, 2, 8, 0, 10, 0, 0, 63, 0}, 5);
+        else
+            launch(PackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, l);
+    }
+    launch(PackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, 8);  // feature_linear
+    // views_linears.0: network.py:63 cat([feature, input_views]): 256 hidden then 27 dir PE -> 128
+    launch(PackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256}, 9);
+    PackSmall s;
+    for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
+    s.bias[8] = b[8];
+    s.bias[9] = b[10];
+    s.alpha_w = w[9];
+    s.alpha_b = b[9];
+    s.rgb_w = w[11];
+    s.rgb_b = b[11];
+    s.packed = packed;
+    pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s);
+    return nrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------
+#define NRF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// One GEMM layer of the chain for this wave's 32 points: out[ob] = bias + sum_k W . kin.
+// `ws` points at this lane's float4 of the layer's first stream step; `ring` already holds
+// steps 0..kPrefetch-1 and is left holding the first kPrefetch steps of whatever follows.
+template <int NOB, int NPRE, int NHID, int NPOST>
+__device__ __forceinline__ void mfma_layer(const float4* __restrict__ ws, float4 (&ring)[kPrefetch],
+                                           const float* __restrict__ bias_h, const f32x16* pre,
+                                           const f32x16* hid, const f32x16* post, f32x16 (&out)[8]) {
+    constexpr int NKB = NPRE + NHID + NPOST;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) out[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const f32x16 x = kb < NPRE ? pre[kb] : (kb < NPRE + NHID ? hid[kb - NPRE] : post[kb - NPRE - NHID]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = (ob * NKB + kb) * 4 + q;
+                const float4 w = ring[s % kPrefetch];
+                ring[s % kPrefetch] = ws[(s + kPrefetch) * 64];
+                out[ob] = NRF_MFMA(w.x, x[4 * q + 0], out[ob]);
+                out[ob] = NRF_MFMA(w.y, x[4 * q + 1], out[ob]);
+                out[ob] = NRF_MFMA(w.z, x[4 * q + 2], out[ob]);
+                out[ob] = NRF_MFMA(w.w, x[4 * q + 3], out[ob]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = fmaxf(v[i], 0.f);
+    return r;
+}
+
+// sin(a) for lane-half 0, cos(a) for lane-half 1, branch-free.  Cody-Waite reduction with a
+// 3-term pi/2 (valid for |a| < 2^17, i.e. |x| < 256 at the 2^9 band; the scene lives in
+// |x| <= far = 6) and degree-7/8 minimax polynomials: max abs error 9.2e-8 over |a| <= 2e4
+// (tests/test_host_logic.py emulates it; torch's own sin is within 7e-8 of exact).
+__device__ __forceinline__ float sin_or_cos(float a, int h) {
+    const float k = rintf(a * 0.63661977236758134308f);
+    float r = fmaf(k, -1.57079637050628662109375f, a);
+    r = fmaf(k, 7.54978941586159635335e-08f, r);
+    r = fmaf(k, 5.39030285815811905e-15f, r);
+    const float z = r * r;
+    float sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    sp = fmaf(sp * z, r, r);
+    float cp = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    cp = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
+    const int q = int(k) + h;  // cos(a) = sin(a + pi/2)
+    const float v = (q & 1) ? cp : sp;
+    return (q & 2) ? -v : v;
+}
+
+// 16 encoding slots of one k-block: trig part for slots n < 3L, then the raw inputs.
+template <int L, int KB>
+__device__ __forceinline__ f32x16 encode_block(float x, float y, float z, int h) {
+    f32x16 r;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int n = KB * 16 + t;
+        float v;
+        if (n < 3 * L) {
+            const float c = (n % 3) == 0 ? x : ((n % 3) == 1 ? y : z);
+            v = sin_or_cos(c * float(1 << (n / 3)), h);
+        } else if (n == 3 * L) {
+            v = h ? y : x;
+        } else if (n == 3 * L + 1) {
+            v = h ? 0.f : z;
+        } else {
+            v = 0.f;
+        }
+        r[t] = v;
+    }
+    return r;
+}
+
+template <bool RAYS>
+__global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict__ packed,
+                                                         const float* __restrict__ a0,  // rays_o | pts
+                                                         const float* __restrict__ a1,  // rays_d | dirs
+                                                         const float* __restrict__ zbuf, int64_t z_stride,
+                                                         int tiles_per_ray, int64_t n_points,
+                                                         float4* __restrict__ raw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= n_points) return;  // wave-uniform
+    const int j = lane & 31, h = lane >> 5;
+
+    // start the weight stream first: its latency hides under the encoding below
+    const float4* ws = reinterpret_cast<const float4*>(packed) + lane;
+    float4 ring[kPrefetch];
+#pragma unroll
+    for (int i = 0; i < kPrefetch; ++i) ring[i] = ws[i * 64];
+
+    int64_t pidx = tile * 32 + j;
+    const bool valid = pidx < n_points;
+    if (!valid) pidx = n_points - 1;
+    float px, py, pz, dx, dy, dz;
+    if (RAYS) {
+        const int64_t ray = tile / tiles_per_ray;
+        const int s0 = int(tile - ray * tiles_per_ray) * 32;
+        const float ox = a0[ray * 3 + 0], oy = a0[ray * 3 + 1], oz = a0[ray * 3 + 2];
+        dx = a1[ray * 3 + 0], dy = a1[ray * 3 + 1], dz = a1[ray * 3 + 2];
+        // volume_renderer.py:230; torch-CPU's norm over 3 elements is this fma chain (bit-exact dhat
+        // matters: a 1-ulp change of the point moves the 2^9-band encoding by ~2e-4)
+        const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
+        const float zz = zbuf[ray * z_stride + s0 + j];
+        px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231, separate mul and add like torch
+        py = __fadd_rn(oy, __fmul_rn(zz, dy));
+        pz = __fadd_rn(oz, __fmul_rn(zz, dz));
+    } else {
+        px = a0[pidx * 3 + 0], py = a0[pidx * 3 + 1], pz = a0[pidx * 3 + 2];
+        dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
+    }
+
+    f32x16 pe[2], dpe[1];
+    pe[0] = encode_block<10, 0>(px, py, pz, h);
+    pe[1] = encode_block<10, 1>(px, py, pz, h);
+    dpe[0] = encode_block<4, 0>(dx, dy, dz, h);
+
+    const float* bias_h = packed + kOffBias + h * 16;  // [layer][ob][h][16]
+    f32x16 in[8], out[8];
+
+    // pts_linears.0
+    mfma_layer<8, 2, 0, 0>(ws, ring, bias_h, pe, nullptr, nullptr, out);
+    ws += kStepsL0 * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) in[i] = relu16(out[i]);
+
+    float sigma = 0.f;
+    for (int li = 1; li <= 8; ++li) {
+        if (li == 5) {
+            mfma_layer<8, 2, 8, 0>(ws, ring, bias_h + li * 256, pe, in, nullptr, out);
+            ws += kStepsSkip * 64;
+        } else {
+            mfma_layer<8, 0, 8, 0>(ws, ring, bias_h + li * 256, nullptr, in, nullptr, out);
+            ws += kStepsHidden * 64;
+        }
+        if (li == 8) {
+            // alpha_linear on h7 (still in `in`): VALU dot over this half's 128 features
+            const float* aw = packed + kOffAlphaW + h * 16;
+            float acc = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = fmaf(w[t], in[kb][t], acc);
+            }
+            sigma = acc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) in[i] = out[i];  // feature_linear: no activation
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) in[i] = relu16(out[i]);
+        }
+    }
+
+    // views_linears.0 on cat([feature, dir PE]) -> 128, relu
+    mfma_layer<4, 0, 8, 1>(ws, ring, bias_h + 9 * 256, nullptr, in, dpe, out);
+    float r = 0.f, g = 0.f, b = 0.f;
+    {
+        const float* rw = packed + kOffRgbW + h * 16;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const f32x16 hv = relu16(out[kb]);
+            const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
+            const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
+            const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                r = fmaf(w0[t], hv[t], r);
+                g = fmaf(w1[t], hv[t], g);
+                b = fmaf(w2[t], hv[t], b);
+            }
+        }
+    }
+    // combine the two lane halves (each holds half of every dot product)
+    r += __shfl_xor(r, 32);
+    g += __shfl_xor(g, 32);
+    b += __shfl_xor(b, 32);
+    sigma += __shfl_xor(sigma, 32);
+    if (h == 0 && valid) {
+        const float4 rb = *reinterpret_cast<const float4*>(packed + kOffRgbB);
+        const float ab = packed[kOffAlphaB];
+        raw[pidx] = make_float4(r + rb.x, g + rb.y, b + rb.z, sigma + ab);
+    }
+}
+
+static int check_common(const float* packed, const void* a, const void* b, const void* raw) {
+    if (!packed || !a || !b || !raw) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    return NRF_OK;
+}
+
+NRF_EXPORT int nrf_mlp_forward_rays(const float* packed, const float* rays_o, const float* rays_d, const float* z,
+                                    int64_t z_stride, int64_t n_rays, int n_samples, float* raw,
+                                    nrf_stream_t stream) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;  // empty batch: nothing to read or write, pointers may be NULL
+    if (int st = check_common(packed, rays_o, rays_d, raw)) return st;
+    if (!z) return NRF_ERR_NULL;
+    const int tiles_per_ray = n_samples / 32;
+    const int64_t tiles = n_rays * tiles_per_ray;
+    const int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    mlp_fwd_kernel<true><<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        packed, rays_o, rays_d, z, z_stride, tiles_per_ray, tiles * 32, reinterpret_cast<float4*>(raw));
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_mlp_forward_points(const float* packed, const float* pts, const float* dirs, int64_t n_points,
+                                      float* raw, nrf_stream_t stream) {
+    if (n_points < 0) return NRF_ERR_SHAPE;
+    if (n_points == 0) return NRF_OK;
+    if (int st = check_common(packed, pts, dirs, raw)) return st;
+    const int64_t tiles = (n_points + 31) / 32;
+    const int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    mlp_fwd_kernel<false><<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        packed, pts, dirs, nullptr, 0, 1, n_points, reinterpret_cast<float4*>(raw));
+    return nrf_launch_status();
+}

@@ -1,0 +1,63 @@
+// Shared definitions of the HIP sources behind include/nerf_amd.h (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nerf_amd.h"
+
+#define NRF_EXPORT extern "C" __attribute__((visibility("default")))
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int nrf_launch_status() {
+    return hipGetLastError() == hipSuccess ? NRF_OK : NRF_ERR_LAUNCH;
+}
+
+static inline bool nrf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------
+// Packed ("streaming") layout of one 8x256 MLP, in floats.  See mlp_fp32.hip.
+//
+// The A-operand stream: one *step* = 256 floats = 1 KiB = one float4 per lane = the weight
+// operands of 4 consecutive v_mfma_f32_32x32x2_f32.  Layers are contiguous so a wavefront
+// reads the whole network as one linear stream.
+// ------------------------------------------------------------------------------------
+namespace nrf {
+
+constexpr int kStepFloats = 256;
+constexpr int kStepsL0 = 8 * 2 * 4;      // 8 out blocks x 2 PE k-blocks x 4
+constexpr int kStepsHidden = 8 * 8 * 4;  // 256 -> 256
+constexpr int kStepsSkip = 8 * 10 * 4;   // (64 PE + 256) -> 256
+constexpr int kStepsViews = 4 * 9 * 4;   // (256 + 32 dir PE) -> 128
+constexpr int kStreamSteps = kStepsL0 + 7 * kStepsHidden + kStepsSkip + kStepsViews;  // 2320
+constexpr int kPrefetch = 8;             // ring depth of the weight stream (steps)
+
+// stream offsets (in steps) of each MFMA layer: pts0..7, feature, views
+constexpr int kLayerStep[10] = {
+    0,
+    kStepsL0,
+    kStepsL0 + 1 * kStepsHidden,
+    kStepsL0 + 2 * kStepsHidden,
+    kStepsL0 + 3 * kStepsHidden,
+    kStepsL0 + 4 * kStepsHidden,                 // pts5 (skip)
+    kStepsL0 + 4 * kStepsHidden + kStepsSkip,    // pts6
+    kStepsL0 + 5 * kStepsHidden + kStepsSkip,    // pts7
+    kStepsL0 + 6 * kStepsHidden + kStepsSkip,    // feature
+    kStepsL0 + 7 * kStepsHidden + kStepsSkip,    // views
+};
+
+// after the stream (+ kPrefetch steps of zero padding so the ring may run past the end):
+constexpr int64_t kOffBias = int64_t(kStreamSteps + kPrefetch) * kStepFloats;  // 9 x 256 + 128, order [ob][h][r]
+constexpr int64_t kOffAlphaW = kOffBias + 9 * 256 + 128;                       // 256, order [kb][h][t]
+constexpr int64_t kOffAlphaB = kOffAlphaW + 256;                               // 16 (1 used)
+constexpr int64_t kOffRgbW = kOffAlphaB + 16;                                  // 3 x 128, order [c][kb][h][t]
+constexpr int64_t kOffRgbB = kOffRgbW + 3 * 128;                               // 16 (3 used)
+constexpr int64_t kPackedFloats = kOffRgbB + 16;
+constexpr int kSmallFloats = int(kPackedFloats - kOffBias);
+
+// row of a 32x32 MFMA accumulator held in register t of lane-half h
+__host__ __device__ constexpr int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
+
+}  // namespace nrf

@@ -1,0 +1,146 @@
+"""Tensor-level wrappers over the C ABI: marshal ``tensor.data_ptr()`` + sizes + the current
+HIP stream into libnerf_amd.so.  No arithmetic happens here; torch only owns the memory."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+# order of include/nerf_amd.h `w[12]` / `b[12]` (reference state-dict names, network.py:22-47)
+LAYER_NAMES = tuple([f"pts_linears.{i}" for i in range(8)] +
+                    ["feature_linear", "alpha_linear", "views_linears.0", "rgb_linear"])
+LAYER_SHAPES = ((256, 63), (256, 256), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256),
+                (256, 256), (1, 256), (128, 283), (3, 128))
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.NrfError(f"{name}: expected a cuda tensor (the render path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.NrfError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def packed_floats() -> int:
+    return int(lib().nrf_packed_floats())
+
+
+def pack_weights(weights, biases, out: torch.Tensor | None = None) -> torch.Tensor:
+    """12 (out,in) weight tensors + 12 biases (LAYER_NAMES order) -> packed streaming buffer."""
+    assert len(weights) == 12 and len(biases) == 12
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    bs = [_f32(b.detach(), "bias") for b in biases]
+    for w, b, shp in zip(ws, bs, LAYER_SHAPES):
+        if tuple(w.shape) != shp or tuple(b.shape) != (shp[0],):
+            raise _lib.NrfError(f"unexpected layer shape {tuple(w.shape)} (want {shp}): only the 8x256 NeRF MLP "
+                                "with 10/4-frequency encodings is supported")
+    dev = ws[0].device
+    if out is None:
+        out = torch.empty(packed_floats(), dtype=torch.float32, device=dev)
+    wp = (C.c_void_p * 12)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * 12)(*[b.data_ptr() for b in bs])
+    with torch.cuda.device(dev):
+        check(lib().nrf_pack_weights(wp, bp, _ptr(out), _stream(out)), "nrf_pack_weights")
+    return out
+
+
+def pack_state_dict(sd: dict, prefix: str, device) -> torch.Tensor:
+    ws = [torch.as_tensor(sd[f"{prefix}.{n}.weight"]).to(device=device, dtype=torch.float32) for n in LAYER_NAMES]
+    bs = [torch.as_tensor(sd[f"{prefix}.{n}.bias"]).to(device=device, dtype=torch.float32) for n in LAYER_NAMES]
+    return pack_weights(ws, bs)
+
+
+def raygen(c2w, H: int, W: int, focal: float, device, first_ray: int = 0, n_rays: int | None = None,
+           pixel_index: torch.Tensor | None = None):
+    c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float64)[:3, :4])
+    flat = np.ascontiguousarray(np.concatenate([c2w, np.zeros((0, 4))]).reshape(-1))
+    # the C side reads rows of 4: [r00 r01 r02 t0, r10 ...]
+    if pixel_index is not None:
+        n = int(pixel_index.numel())
+        pixel_index = pixel_index.to(device=device, dtype=torch.int64).contiguous()
+    else:
+        n = H * W - first_ray if n_rays is None else int(n_rays)
+    xyz = torch.empty((n, 3), dtype=torch.float32, device=device)
+    dirs = torch.empty((n, 3), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(lib().nrf_raygen(flat.ctypes.data_as(C.c_void_p), H, W, float(focal), first_ray, n,
+                               _ptr(pixel_index), _ptr(xyz), _ptr(dirs), _stream(xyz)), "nrf_raygen")
+    return xyz, dirs
+
+
+def perturb_samples(z: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    u = _f32(u, "u")
+    R, n = u.shape
+    z = _f32(z, "z")
+    stride = 0 if z.ndim == 1 else n
+    out = torch.empty_like(u)
+    with torch.cuda.device(u.device):
+        check(lib().nrf_perturb_samples(_ptr(z), stride, _ptr(u), R, n, _ptr(out), _stream(u)), "nrf_perturb_samples")
+    return out
+
+
+def mlp_forward_rays(packed, rays_o, rays_d, z) -> torch.Tensor:
+    rays_o, rays_d, z = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z, "z")
+    R = rays_o.shape[0]
+    S = z.shape[-1]
+    stride = 0 if z.ndim == 1 else S
+    raw = torch.empty((R, S, 4), dtype=torch.float32, device=rays_o.device)
+    with torch.cuda.device(raw.device):
+        check(lib().nrf_mlp_forward_rays(_ptr(packed), _ptr(rays_o), _ptr(rays_d), _ptr(z), stride, R, S, _ptr(raw),
+                                         _stream(raw)), "nrf_mlp_forward_rays")
+    return raw
+
+
+def mlp_forward_points(packed, pts, dirs) -> torch.Tensor:
+    pts, dirs = _f32(pts, "pts"), _f32(dirs, "dirs")
+    n = pts.shape[0]
+    raw = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(raw.device):
+        check(lib().nrf_mlp_forward_points(_ptr(packed), _ptr(pts), _ptr(dirs), n, _ptr(raw), _stream(raw)),
+              "nrf_mlp_forward_points")
+    return raw
+
+
+def composite(raw, z, white_bkgd: bool = True, want_weights: bool = True):
+    raw, z = _f32(raw, "raw"), _f32(z, "z")
+    R, S = raw.shape[0], raw.shape[1]
+    stride = 0 if z.ndim == 1 else S
+    dev = raw.device
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((R,), dtype=torch.float32, device=dev)
+    acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    w = torch.empty((R, S), dtype=torch.float32, device=dev) if want_weights else None
+    with torch.cuda.device(dev):
+        check(lib().nrf_composite(_ptr(raw), _ptr(z), stride, R, S, int(bool(white_bkgd)), _ptr(rgb), _ptr(depth),
+                                  _ptr(acc), _ptr(w), _stream(raw)), "nrf_composite")
+    return rgb, depth, w, acc
+
+
+def sample_fine(weights, bins, z_coarse, u, u2, u_fine=None, want_debug: bool = False):
+    weights, u, u2 = _f32(weights, "weights"), _f32(u, "u"), _f32(u2, "u2")
+    bins, z_coarse = _f32(bins, "bins"), _f32(z_coarse, "z_coarse")
+    R, nc = weights.shape
+    ni = u.shape[1]
+    dev = weights.device
+    z_out = torch.empty((R, nc + ni), dtype=torch.float32, device=dev)
+    fine = torch.empty((R, ni), dtype=torch.float32, device=dev) if want_debug else None
+    idx = torch.empty((R, ni), dtype=torch.int32, device=dev) if want_debug else None
+    if u_fine is not None:
+        u_fine = _f32(u_fine, "u_fine")
+    with torch.cuda.device(dev):
+        check(lib().nrf_sample_fine(_ptr(weights), _ptr(bins), 0 if bins.ndim == 1 else nc, _ptr(z_coarse),
+                                    0 if z_coarse.ndim == 1 else nc, _ptr(u), _ptr(u2), _ptr(u_fine), R, nc, ni,
+                                    _ptr(z_out), _ptr(fine), _ptr(idx), _stream(weights)), "nrf_sample_fine")
+    return (z_out, fine, idx) if want_debug else z_out

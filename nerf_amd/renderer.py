@@ -1,0 +1,160 @@
+"""Drop-in ``Renderer`` for the reference's ``renderer_module`` plug-in point.
+
+Mirrors /root/reference/src/models/nerf/renderer/volume_renderer.py: ``Renderer(net)``
+(:11-21), ``forward(batch, is_training)`` (:49) and the ``render`` name the callers use
+(src/train/trainers/nerf.py:21, run.py:39, gen_dist_data.py:72), with the classic
+coarse + fine body the reference keeps at :143-153 / :201-334.  All arithmetic runs in
+libnerf_amd.so (HIP, gfx950); this class only owns tensors, the packed-weight cache and
+the random draws, and fails loudly when the library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import NrfError, RenderArgs, check, lib
+from .config import default_cfg
+
+
+def near_far_table(near: float, far: float, n: int) -> np.ndarray:
+    """``near*(1-s) + far*s`` with ``s = linspace(0, 1, n)`` in fp32 (volume_renderer.py:214-215).
+
+    Host-side, 64 entries, identical for every ray when ``perturb == 0``.  Uses torch's
+    two-sided linspace formula in scalar form (start + i*step below the middle,
+    end - (n-1-i)*step above), so the table does not depend on the host's SIMD width.
+    """
+    f = np.float32
+    step = f(f(1.0) / f(n - 1))
+    s = np.array([f(step * f(i)) if i < n // 2 else f(f(1.0) - f(step * f(n - 1 - i))) for i in range(n)], dtype=f)
+    return (f(near) * (f(1.0) - s) + f(far) * s).astype(f)
+
+
+class Renderer(nn.Module):
+    def __init__(self, net, cfg=None):
+        super().__init__()
+        if cfg is None:
+            try:  # inside the reference tree: its global config (volume_renderer.py:8)
+                from src.config import cfg as ref_cfg  # type: ignore
+                cfg = ref_cfg
+            except Exception:
+                cfg = default_cfg()
+        ta = cfg.task_arg
+        self.net = net
+        self.N_samples = int(ta.N_samples)
+        self.N_importance = int(ta.N_importance)
+        self.white_bkgd = ta.white_bkgd
+        self.perturb = ta.perturb
+        self.raw_noise_std = ta.raw_noise_std
+        self.near = ta.near
+        self.far = ta.far
+        self.chunk_size = ta.chunk_size if getattr(ta, "chunk_size", 0) > 0 else 1024
+        if self.raw_noise_std and self.raw_noise_std > 0:
+            # the reference calls an undefined bare add_noise() here (:241, :310) and would crash
+            raise NrfError("raw_noise_std > 0 is not supported (the reference's noise branch is broken)")
+        lib()  # fail now, not at the first frame, if the HIP library is absent
+        # state the reference keeps between the two passes (:216, :220, :285)
+        self.t_bins = None
+        self.coarse_samples = None
+        self.fine_samples = None
+        self.max_rays_per_call = 1 << 20
+        self._packed = {}      # model name -> (version key, packed tensor)
+        self._bins = None
+        self._workspace = None
+
+    # ---- weights ---------------------------------------------------------------------
+    def _packed_model(self, name: str, device) -> torch.Tensor:
+        model = getattr(self.net, name)
+        params = []
+        for ln in ops.LAYER_NAMES:
+            mod = model
+            for part in ln.split("."):
+                mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+            params += [mod.weight, mod.bias]
+        key = tuple((p.data_ptr(), p._version) for p in params) + (str(device),)
+        hit = self._packed.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        buf = hit[1] if hit is not None and hit[1].device == torch.device(device) else None
+        ws = [p if p.device == torch.device(device) else p.to(device) for p in params[0::2]]
+        bs = [p if p.device == torch.device(device) else p.to(device) for p in params[1::2]]
+        buf = ops.pack_weights(ws, bs, out=buf)
+        self._packed[name] = (key, buf)
+        return buf
+
+    # ---- the reference's public surface ------------------------------------------------
+    def render(self, batch, is_training: bool = True):
+        return self.forward(batch, is_training)
+
+    def forward(self, batch, is_training: bool = True):
+        xyz, viewdirs = batch["xyz"], batch["viewdirs"]
+        _ = batch["gt_rgb"]  # the classic path requires the key (:209, :276)
+        if xyz.ndim != 3 or xyz.shape[0] != 1:
+            raise NrfError(f"batch['xyz'] must be (1, R, 3) like the reference's classic path, got {tuple(xyz.shape)}")
+        if not xyz.is_cuda:
+            raise NrfError("batch tensors must be on a GPU: this renderer has no CPU path")
+        if torch.is_grad_enabled() and is_training and any(p.requires_grad for p in self.net.parameters()):
+            raise NotImplementedError("training (autograd) through the HIP renderer is not built yet: "
+                                      "call under torch.no_grad() for inference")
+        dev = xyz.device
+        rays_o = xyz[0].to(torch.float32).contiguous()
+        rays_d = viewdirs[0].to(torch.float32).contiguous()
+        R = rays_o.shape[0]
+        nc, ni = self.N_samples, self.N_importance
+        if self._bins is None or self._bins.device != dev:
+            self._bins = torch.from_numpy(near_far_table(self.near, self.far, nc)).to(dev)
+        self.t_bins = self._bins
+        perturbed = bool(self.perturb > 0 and is_training)
+        # same draw order as the reference: coarse perturb (:348), u (:379), u2 (:389), fine perturb (:348)
+        u_coarse = torch.rand((R, nc), dtype=torch.float32, device=dev) if perturbed else None
+        u = torch.rand((R, ni), device=dev)
+        u2 = torch.rand(R, ni, device=dev)
+        u_fine = torch.rand((R, ni), dtype=torch.float32, device=dev) if perturbed else None
+        out = self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
+        return out
+
+    def render_rays(self, rays_o, rays_d, u, u2, u_coarse=None, u_fine=None):
+        """(R,3) origins / un-normalised dirs + the uniforms -> the reference's output dict."""
+        dev = rays_o.device
+        R = rays_o.shape[0]
+        nc, ni = self.N_samples, self.N_importance
+        if self._bins is None or self._bins.device != dev:
+            self._bins = torch.from_numpy(near_far_table(self.near, self.far, nc)).to(dev)
+        pc = self._packed_model("model", dev)
+        pf = self._packed_model("model_fine", dev)
+        c_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        c_depth = torch.empty((R,), dtype=torch.float32, device=dev)
+        f_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        f_depth = torch.empty((R,), dtype=torch.float32, device=dev)
+        f_acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        L = lib()
+        step = min(R, self.max_rays_per_call)
+        need = int(L.nrf_render_workspace_bytes(step, nc, ni))
+        if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            for r0 in range(0, R, step):
+                n = min(step, R - r0)
+                a = RenderArgs()
+                a.packed_coarse, a.packed_fine = pc.data_ptr(), pf.data_ptr()
+                a.rays_o, a.rays_d = rays_o[r0:].data_ptr(), rays_d[r0:].data_ptr()
+                a.bins = self._bins.data_ptr()
+                a.u, a.u2 = u[r0:].data_ptr(), u2[r0:].data_ptr()
+                a.u_coarse = u_coarse[r0:].data_ptr() if u_coarse is not None else None
+                a.u_fine = u_fine[r0:].data_ptr() if u_fine is not None else None
+                a.n_rays, a.n_coarse, a.n_importance = n, nc, ni
+                a.white_bkgd = int(self.white_bkgd > 0)
+                a.coarse_rgb, a.coarse_depth = c_rgb[r0:].data_ptr(), c_depth[r0:].data_ptr()
+                a.fine_rgb, a.fine_depth, a.fine_acc = f_rgb[r0:].data_ptr(), f_depth[r0:].data_ptr(), f_acc[r0:].data_ptr()
+                a.workspace, a.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
+                check(L.nrf_render(C.byref(a), stream), "nrf_render")
+        return {
+            "coarse_rgb_map": c_rgb, "coarse_depth_map": c_depth,
+            "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc,
+            # north-star aliases
+            "rgb_map": f_rgb, "depth_map": f_depth, "acc_map": f_acc,
+        }

@@ -123,10 +123,16 @@ def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Te
 
 
 def network_forward(sd: dict, pts: torch.Tensor, dirs: torch.Tensor, model: str = "",
-                    chunk: int = 65536) -> torch.Tensor:
+                    chunk: int = 65536, dtype=None) -> torch.Tensor:
     """``Network.forward`` (network.py:171-195). ``pts`` (R,S,3) with ``dirs`` (R,3), or
-    ``pts`` (P,3) with ``dirs`` (P,3).  Returns (..., 4)."""
+    ``pts`` (P,3) with ``dirs`` (P,3).  Returns (..., 4).
+
+    ``dtype=torch.float64`` evaluates encoding + MLP in double from the same fp32 inputs: the
+    yardstick tests use to tell fp32 rounding noise (ours vs the reference's) from a bug."""
     prefix = "model_fine" if model == "fine" else "model"
+    if dtype is not None:
+        sd = {k: v.to(dtype) for k, v in sd.items() if k.startswith(prefix + ".")}
+        pts, dirs = pts.to(dtype), dirs.to(dtype)
     flat = pts.reshape(-1, 3)
     d = dirs[:, None].expand(pts.shape) if pts.ndim == 3 else dirs
     dflat = d.reshape(-1, 3)
