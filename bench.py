@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec and ms per 800x800 frame (64 coarse + 128 fine samples/ray).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one full 800x800 test-view render (BASELINE.json configs[1]: NeRF coarse + fine,
+fp32 MLP, random-init weights, synthetic orbit camera): ray generation -> coarse MLP ->
+compositing -> importance resampling + merge -> fine MLP -> compositing, everything on the
+GPU, inputs (pose, weights) resident before the timed region.  With N ranks every rank
+renders its own view per step (views of the 200-view orbit are sharded round-robin, no
+data-path collective): weak scaling, value = all rays of all ranks / max-over-ranks time.
+
+The same JSON line carries
+  roofline      the dominant kernel (mlp_fwd_kernel, MFMA-bound): algorithmic FLOPs per launch
+                / its mean launch time, measured with HIP events on the launch stream inside
+                the timed region; peak = fp32 MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md)
+  cpu_baseline  oracle/ (the CPU restatement of the reference) timed on this host's cores
+                on a bounded sample of the same rays (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 800
+N_COARSE, N_IMPORTANCE = 64, 128
+MACS_PER_POINT = 593_408
+FLOP_PER_POINT = 2 * MACS_PER_POINT
+FP32_MFMA_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds: float):
+    """Oracle render of 1024-ray slices of the bench view until ~`seconds` of CPU time."""
+    from oracle import nerf_oracle as O
+    from nerf_amd.weights import make_state_dict
+    from nerf_amd.camera import pose_spherical, LEGO_CAMERA_ANGLE_X
+    sd = make_state_dict(0, 30.0, 2.0)
+    o, d = O.raygen(pose_spherical(0.0), H, W, LEGO_CAMERA_ANGLE_X)
+    rng = np.random.Generator(np.random.PCG64(0))
+    chunk, done, t0 = 1024, 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            r0 = 400 * W + done          # central rows: rays that cross the scene box
+            u = rng.random((chunk, N_IMPORTANCE), dtype=np.float32)
+            u2 = rng.random((chunk, N_IMPORTANCE), dtype=np.float32)
+            O.render(sd, o[r0:r0 + chunk], d[r0:r0 + chunk], u=u, u2=u2)
+            done += chunk
+            el = time.perf_counter() - t0
+            if el >= seconds or done >= 64 * chunk:
+                break
+    return {"value": done / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} rays of the same 800x800 view (rows 400+), coarse+fine, oracle/nerf_oracle.py "
+                      f"on torch-CPU fp32, {el:.1f} s; host has {os.cpu_count()} logical CPUs",
+            "ms_per_frame_extrapolated": 1e3 * H * W * el / done}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from nerf_amd import ops
+    from nerf_amd.camera import test_set_poses, focal_from_angle
+    from nerf_amd.config import default_cfg
+    from nerf_amd.network import Network
+    from nerf_amd.renderer import Renderer
+    from nerf_amd.weights import make_state_dict
+
+    net = Network()
+    net.load_state_dict(make_state_dict(0, 30.0, 2.0))   # random init, density rescaled so rays terminate
+    net.to(dev)
+    renderer = Renderer(net, default_cfg(perturb=0))
+    poses = test_set_poses(200)
+    focal = focal_from_angle(W)
+    R = H * W
+    events = {}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+
+    def step(k, ev):
+        c2w = poses[(k * world + rank) % len(poses)]
+        rays_o, rays_d = ops.raygen(c2w, H, W, focal, dev)
+        u = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
+        u2 = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
+        return renderer.render_rays_staged(rays_o, rays_d, u, u2, events=ev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for k in range(args.warmup):
+            out = step(k, None)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            out = step(args.warmup + k, events)
+        sync()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out["fine_rgb_map"]).all()
+
+    def mean_ms(name):
+        return float(np.mean([a.elapsed_time(b) for a, b in events[name]]))
+
+    ms_mlp_c, ms_mlp_f = mean_ms("mlp_coarse"), mean_ms("mlp_fine")
+    ms_cmp_c, ms_cmp_f, ms_smp = mean_ms("composite_coarse"), mean_ms("composite_fine"), mean_ms("sample_fine")
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        flop_launch = 0.5 * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT   # mean of the 2 launches
+        ms_launch = 0.5 * (ms_mlp_c + ms_mlp_f)
+        achieved = flop_launch / (ms_launch * 1e-3) / 1e12
+        cmp_bytes = R * ((N_COARSE + N_IMPORTANCE) * 20 + 20)
+        line = {
+            "metric": "rays/sec (full 800x800 frame, 64 coarse + 128 fine samples/ray)",
+            "value": world * R * args.steps / elapsed,
+            "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "ms_per_frame": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
+            "config": {"workload": "BASELINE configs[1]: full 800x800 lego test-view render, NeRF coarse+fine, fp32, "
+                                   "one view per rank per step", "rays_per_frame": R, "n_coarse": N_COARSE,
+                       "n_importance": N_IMPORTANCE, "sharding": f"views round-robin over {world} rank(s)"},
+            "roofline": {"kernel": "mlp_fwd_kernel<true> (fused points + PE + 8x256 MLP, fp32 MFMA)",
+                         "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "flop_per_launch": flop_launch, "ms_per_launch": ms_launch,
+                         "ms_coarse_launch": ms_mlp_c, "ms_fine_launch": ms_mlp_f},
+            "roofline_composite": {"kernel": "composite_kernel<3> (fine pass)", "bound": "hbm",
+                                   "achieved": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_cmp_f,
+                                   "bytes_per_launch": cmp_bytes},
+            "stage_ms": {"mlp_coarse": ms_mlp_c, "composite_coarse": ms_cmp_c, "sample_fine": ms_smp,
+                         "mlp_fine": ms_mlp_f, "composite_fine": ms_cmp_f},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,9 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise NrfError(f"{LIB_PATH} not built: run `make -C nerf_amd/csrc` (hipcc --offload-arch=gfx950); "
                        "there is no CPU/PyTorch fallback for the render path")
+    # torch bundles its own libamdhip64.so.7; it must be the one already mapped when our library's
+    # NEEDED entry is resolved, or the process ends up with two HIP runtimes (launches then fail).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.nrf_version.restype = INT
     L.nrf_strerror.restype = C.c_char_p

@@ -97,6 +97,7 @@ NRF_EXPORT int nrf_composite(const float* raw, const float* z, int64_t z_stride,
         composite_kernel<N><<<dim3((unsigned)blocks), 256, 0, stream>>>(r4, z, z_stride, n_rays, white_bkgd, rgb_map, \
                                                                         depth_map, acc_map, weights);      \
         break;
+    nrf_launch_begin();
     switch (n_samples / 64) {
         NRF_COMPOSITE_CASE(1)
         NRF_COMPOSITE_CASE(2)

@@ -107,6 +107,7 @@ NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, fl
         if (!w[i] || !b[i]) return NRF_ERR_NULL;
     if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    nrf_launch_begin();
     auto launch = [&](PackLayer p, int layer_slot) {
         p.dst = packed + int64_t(kLayerStep[layer_slot]) * kStepFloats;
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 4 * kStepFloats;
@@ -350,6 +351,7 @@ NRF_EXPORT int nrf_mlp_forward_rays(const float* packed, const float* rays_o, co
     const int64_t tiles = n_rays * tiles_per_ray;
     const int64_t blocks = (tiles + 3) / 4;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    nrf_launch_begin();
     mlp_fwd_kernel<true><<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
         packed, rays_o, rays_d, z, z_stride, tiles_per_ray, tiles * 32, reinterpret_cast<float4*>(raw));
     return nrf_launch_status();
@@ -363,6 +365,7 @@ NRF_EXPORT int nrf_mlp_forward_points(const float* packed, const float* pts, con
     const int64_t tiles = (n_points + 31) / 32;
     const int64_t blocks = (tiles + 3) / 4;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    nrf_launch_begin();
     mlp_fwd_kernel<false><<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
         packed, pts, dirs, nullptr, 0, 1, n_points, reinterpret_cast<float4*>(raw));
     return nrf_launch_status();

@@ -11,6 +11,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// hipGetLastError() is sticky per host thread and also reports errors left behind by the caller's
+// own HIP calls (torch leaves benign ones, e.g. hipErrorNotReady from event queries), so every
+// entry point clears it before its first launch and reads it after its last.
+static inline void nrf_launch_begin() { (void)hipGetLastError(); }
 static inline int nrf_launch_status() {
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_ERR_LAUNCH;
 }

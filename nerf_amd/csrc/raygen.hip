@@ -51,6 +51,7 @@ NRF_EXPORT int nrf_raygen(const double* c2w, int H, int W, double focal, int64_t
     cam.half_h = H / 2.0;
     const int64_t blocks = (n_rays + 255) / 256;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    nrf_launch_begin();
     raygen_kernel<<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(cam, W, first_ray, n_rays,
                                                                                       pixel_index, xyz, viewdirs);
     return nrf_launch_status();

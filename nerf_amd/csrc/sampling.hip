@@ -162,6 +162,7 @@ NRF_EXPORT int nrf_perturb_samples(const float* z_in, int64_t z_stride, const fl
     if (n_rays == 0) return NRF_OK;
     const int64_t blocks = (n_rays * n + 255) / 256;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    nrf_launch_begin();
     perturb_kernel<<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(z_in, z_stride, u, n_rays, n, z_out);
     return nrf_launch_status();
 }
@@ -180,6 +181,7 @@ NRF_EXPORT int nrf_sample_fine(const float* weights, const float* bins, int64_t 
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const dim3 grid((unsigned)blocks);
+    nrf_launch_begin();
     switch (n_importance / 64) {
         case 1:
             sample_fine_kernel<1><<<grid, 256, 0, stream>>>(weights, bins, bins_stride, z_coarse, zc_stride, u, u2, u_fine,

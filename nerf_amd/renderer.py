@@ -116,6 +116,41 @@ class Renderer(nn.Module):
         out = self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
         return out
 
+    def render_rays_staged(self, rays_o, rays_d, u, u2, u_coarse=None, u_fine=None, events=None):
+        """Same kernels, same order as nrf_render, but one C-ABI call per stage so a profiler
+        hook can bracket each stage.  ``events``: dict name -> list of (start, end)
+        ``torch.cuda.Event`` pairs appended per stage (recorded on the launch stream)."""
+        dev = rays_o.device
+        nc = self.N_samples
+        if self._bins is None or self._bins.device != dev:
+            self._bins = torch.from_numpy(near_far_table(self.near, self.far, nc)).to(dev)
+        pc = self._packed_model("model", dev)
+        pf = self._packed_model("model_fine", dev)
+        white = self.white_bkgd > 0
+
+        def stage(name, fn, *a, **k):
+            if events is None:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            events.setdefault(name, []).append((e0, e1))
+            return out
+
+        zc = self._bins if u_coarse is None else stage("perturb", ops.perturb_samples, self._bins, u_coarse)
+        raw = stage("mlp_coarse", ops.mlp_forward_rays, pc, rays_o, rays_d, zc)
+        c_rgb, c_depth, w_c, _ = stage("composite_coarse", ops.composite, raw, zc, white, True)
+        z_f = stage("sample_fine", ops.sample_fine, w_c, self._bins, zc, u, u2, u_fine)
+        del raw
+        raw = stage("mlp_fine", ops.mlp_forward_rays, pf, rays_o, rays_d, z_f)
+        f_rgb, f_depth, _, f_acc = stage("composite_fine", ops.composite, raw, z_f, white, False)
+        return {
+            "coarse_rgb_map": c_rgb, "coarse_depth_map": c_depth,
+            "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc,
+            "rgb_map": f_rgb, "depth_map": f_depth, "acc_map": f_acc,
+        }
+
     def render_rays(self, rays_o, rays_d, u, u2, u_coarse=None, u_fine=None):
         """(R,3) origins / un-normalised dirs + the uniforms -> the reference's output dict."""
         dev = rays_o.device
