@@ -142,40 +142,129 @@ NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, fl
 // ------------------------------------------------------------------------------------
 #define NRF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// One GEMM layer of the chain for this wave's 32 points: out[ob] = bias + sum_k W . kin.
-// `ws` points at this lane's float4 of the layer's first stream step; `ring` already holds
-// steps 0..kPrefetch-1 and is left holding the first kPrefetch steps of whatever follows.
-template <int NOB, int NPRE, int NHID, int NPOST>
-__device__ __forceinline__ void mfma_layer(const float4* __restrict__ ws, float4 (&ring)[kPrefetch],
-                                           const float* __restrict__ bias_h, const f32x16* pre,
-                                           const f32x16* hid, const f32x16* post, f32x16 (&out)[8]) {
-    constexpr int NKB = NPRE + NHID + NPOST;
+namespace {
+
+// The weight stream reaches the matrix cores through an LDS ring shared by the workgroup's 4
+// waves: 16-step (16 KiB) chunks, filled by global_load_lds_dwordx4 (LDS-DMA, no VGPRs) kRing-1
+// chunks ahead of use, one raw s_barrier per chunk and a COUNTED vmcnt so the prefetches stay in
+// flight across it.  The kernel is persistent (one workgroup per CU) and the stream wraps, so
+// the ring never drains between tiles.  Every layer is a whole number of chunks.
+constexpr int kChunkSteps = 16;
+constexpr int kChunkBytes = kChunkSteps * kStepFloats * 4;  // 16 KiB
+constexpr int kRing = 5;
+constexpr int kChunks = kStreamSteps / kChunkSteps;  // 145
+static_assert(kStreamSteps % kChunkSteps == 0, "layers must be chunk aligned");
+static_assert(kStepsL0 % kChunkSteps == 0 && kStepsHidden % kChunkSteps == 0 && kStepsSkip % kChunkSteps == 0 &&
+              kStepsViews % kChunkSteps == 0, "layers must be chunk aligned");
+constexpr int kLdsConstOff = kRing * kChunkBytes;              // biases + head weights live after the ring
+constexpr int kLdsBytes = kLdsConstOff + kSmallFloats * 4;     // 80 KiB + 12.1 KiB
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+
+struct WeightStream {
+    const char* gnext;  // per lane: address of this lane's 16 B of piece 4w of the next chunk to prefetch
+    const char* gbegin; // same for chunk 0
+    const char* gend;   // same for chunk kChunks (one past the end: wrap point)
+    unsigned lds_base;  // LDS byte address of smem + wave * 4 KiB (this wave fills pieces 4w..4w+3)
+    char* smem;
+    int pf_slot, rd_slot;
+};
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0 + 1 KiB).
+// Inline asm on purpose: hipcc's waitcnt pass orders every ds_read behind ALL outstanding
+// LDS-DMA it knows of (s_waitcnt vmcnt(0)), which would serialise the ring; issued from asm the
+// loads are invisible to it and are ordered by ws_next_chunk's counted vmcnt + barrier instead.
+__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+__device__ __forceinline__ void ws_prefetch(WeightStream& st) {
+    const unsigned l = st.lds_base + unsigned(st.pf_slot) * kChunkBytes;
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) out[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+    for (int j = 0; j < 4; ++j) glds16(st.gnext + j * 1024, l + j * 1024);
+    const char* nx = st.gnext + kChunkBytes;
+    st.gnext = nx == st.gend ? st.gbegin : nx;
+    // keep the address a run-time value: the schedule repeats every tile, and LICM would otherwise
+    // hoist all 145 chunk addresses out of the tile loop and spill them
+    asm volatile("" : "+v"(st.gnext));
+    st.pf_slot = st.pf_slot + 1 == kRing ? 0 : st.pf_slot + 1;
+}
+
+// Make the next chunk readable: my own 4 pieces of it have landed once at most 4*(kRing-2)
+// younger VMEM ops are outstanding; the barrier then covers the other waves' pieces and also
+// says every wave is done reading the previous chunk, whose slot is refilled right away.
+__device__ __forceinline__ const float4* ws_next_chunk(WeightStream& st, int lane) {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(4 * (kRing - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    ws_prefetch(st);
+    st.rd_slot = st.rd_slot + 1 == kRing ? 0 : st.rd_slot + 1;
+    return reinterpret_cast<const float4*>(st.smem + st.rd_slot * kChunkBytes) + lane;
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float t;  // one v_max_f32 (fmaxf() costs a second, canonicalising v_max for signalling NaNs)
+        asm("v_max_f32 %0, 0, %1" : "=v"(t) : "v"(v[i]));
+        r[i] = t;
+    }
+    return r;
+}
+
+// One GEMM layer of the chain for this wave's 32 points: out[ob] = act(bias + sum_k W . kin).
+// Layers ping-pong between two register sets, nothing is copied.  The activation of output
+// block ob is applied in place AFTER the first MFMAs of block ob+1 have been issued, so the VALU
+// work runs under the matrix pipe; the last block's activation is left to the consumer
+// (PEND_IN: relu hid[NHID-1] the same way at the start of the next layer).
+template <int NOB, int NPRE, int NHID, int NPOST, bool RELU, bool PEND_IN>
+__device__ __forceinline__ void mfma_layer(WeightStream& st, int lane, const float* bias_h, const f32x16* pre,
+                                           f32x16* hid, const f32x16* post, f32x16* out) {
+    constexpr int NKB = NPRE + NHID + NPOST;
+    constexpr int NS = NOB * NKB * 4;
+    static_assert(NS % kChunkSteps == 0, "layer must be a whole number of chunks");
+    static_assert(!PEND_IN || NPRE + NHID > 1, "the pending block must not be the first one consumed");
+    // The weights of step s+1 are read from LDS before the MFMAs of step s are issued (the read
+    // latency hides under 256 matrix-core cycles); the ring hand-over for the next chunk is done
+    // ahead of a chunk's LAST step for the same reason.
+    const float4* rd = ws_next_chunk(st, lane);
+    float4 w = rd[0];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
+        out[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const f32x16 x = kb < NPRE ? pre[kb] : (kb < NPRE + NHID ? hid[kb - NPRE] : post[kb - NPRE - NHID]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int s = (ob * NKB + kb) * 4 + q;
-                const float4 w = ring[s % kPrefetch];
-                ring[s % kPrefetch] = ws[(s + kPrefetch) * 64];
+                float4 wn = w;
+                if (s + 1 < NS) {
+                    if ((s + 1) % kChunkSteps == 0) rd = ws_next_chunk(st, lane);
+                    wn = rd[((s + 1) % kChunkSteps) * 64];
+                }
                 out[ob] = NRF_MFMA(w.x, x[4 * q + 0], out[ob]);
                 out[ob] = NRF_MFMA(w.y, x[4 * q + 1], out[ob]);
                 out[ob] = NRF_MFMA(w.z, x[4 * q + 2], out[ob]);
                 out[ob] = NRF_MFMA(w.w, x[4 * q + 3], out[ob]);
+                w = wn;
+                if (kb == 0 && q == 0) {  // deferred activations, now covered by the MFMAs just issued
+                    if (RELU && ob > 0) out[ob - 1] = relu16(out[ob - 1]);
+                    if (PEND_IN && ob == 0) hid[NHID - 1] = relu16(hid[NHID - 1]);
+                }
             }
         }
     }
-}
-
-__device__ __forceinline__ f32x16 relu16(f32x16 v) {
-    f32x16 r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = fmaxf(v[i], 0.f);
-    return r;
 }
 
 // sin(a) for lane-half 0, cos(a) for lane-half 1, branch-free.  Cody-Waite reduction with a
@@ -184,9 +273,9 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 // (tests/test_host_logic.py emulates it; torch's own sin is within 7e-8 of exact).
 __device__ __forceinline__ float sin_or_cos(float a, int h) {
     const float k = rintf(a * 0.63661977236758134308f);
-    float r = fmaf(k, -1.57079637050628662109375f, a);
-    r = fmaf(k, 7.54978941586159635335e-08f, r);
-    r = fmaf(k, 5.39030285815811905e-15f, r);
+    float r = fmaf(k, __uint_as_float(0xbfc90fdau), a);  // -1.570796251296997
+    r = fmaf(k, __uint_as_float(0xb3a22168u), r);        // -7.549789415861596e-08
+    r = fmaf(k, __uint_as_float(0xa7c234c4u), r);        // -5.390302529957765e-15
     const float z = r * r;
     float sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
     sp = fmaf(sp * z, r, r);
@@ -220,124 +309,148 @@ __device__ __forceinline__ f32x16 encode_block(float x, float y, float z, int h)
     return r;
 }
 
-template <bool RAYS>
+// Persistent: gridDim.x <= number of CUs, one 4-wave workgroup per CU, one wave per SIMD.
+// Tile group tg = 4 consecutive 32-point tiles, one per wave; all waves run every group (the
+// barriers of the weight ring are workgroup-wide), waves past the end just do not store.
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict__ packed,
                                                          const float* __restrict__ a0,  // rays_o | pts
                                                          const float* __restrict__ a1,  // rays_d | dirs
                                                          const float* __restrict__ zbuf, int64_t z_stride,
-                                                         int tiles_per_ray, int64_t n_points,
-                                                         float4* __restrict__ raw) {
+                                                         int tiles_per_ray, int rays_mode, int64_t n_points,
+                                                         int64_t n_groups, float4* __restrict__ raw) {
+    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
     const int lane = threadIdx.x & 63;
-    const int64_t tile = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (tile * 32 >= n_points) return;  // wave-uniform
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    // start the weight stream first: its latency hides under the encoding below
-    const float4* ws = reinterpret_cast<const float4*>(packed) + lane;
-    float4 ring[kPrefetch];
-#pragma unroll
-    for (int i = 0; i < kPrefetch; ++i) ring[i] = ws[i * 64];
-
-    int64_t pidx = tile * 32 + j;
-    const bool valid = pidx < n_points;
-    if (!valid) pidx = n_points - 1;
-    float px, py, pz, dx, dy, dz;
-    if (RAYS) {
-        const int64_t ray = tile / tiles_per_ray;
-        const int s0 = int(tile - ray * tiles_per_ray) * 32;
-        const float ox = a0[ray * 3 + 0], oy = a0[ray * 3 + 1], oz = a0[ray * 3 + 2];
-        dx = a1[ray * 3 + 0], dy = a1[ray * 3 + 1], dz = a1[ray * 3 + 2];
-        // volume_renderer.py:230; torch-CPU's norm over 3 elements is this fma chain (bit-exact dhat
-        // matters: a 1-ulp change of the point moves the 2^9-band encoding by ~2e-4)
-        const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-        dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
-        const float zz = zbuf[ray * z_stride + s0 + j];
-        px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231, separate mul and add like torch
-        py = __fadd_rn(oy, __fmul_rn(zz, dy));
-        pz = __fadd_rn(oz, __fmul_rn(zz, dz));
-    } else {
-        px = a0[pidx * 3 + 0], py = a0[pidx * 3 + 1], pz = a0[pidx * 3 + 2];
-        dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
+    // biases and head weights: global -> LDS once per workgroup (plain loads, before any LDS-DMA)
+    {
+        const float4* src = reinterpret_cast<const float4*>(packed + kOffBias);
+        float4* dst = reinterpret_cast<float4*>(smem + kLdsConstOff);
+        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
     }
+    __syncthreads();
+    const float* cst = reinterpret_cast<const float*>(smem + kLdsConstOff);  // same offsets as packed + kOffBias
+    const float* bias_h = cst + h * 16;                                      // [layer][ob][h][16]
 
-    f32x16 pe[2], dpe[1];
-    pe[0] = encode_block<10, 0>(px, py, pz, h);
-    pe[1] = encode_block<10, 1>(px, py, pz, h);
-    dpe[0] = encode_block<4, 0>(dx, dy, dz, h);
-
-    const float* bias_h = packed + kOffBias + h * 16;  // [layer][ob][h][16]
-    f32x16 in[8], out[8];
-
-    // pts_linears.0
-    mfma_layer<8, 2, 0, 0>(ws, ring, bias_h, pe, nullptr, nullptr, out);
-    ws += kStepsL0 * 64;
+    WeightStream st;
+    st.gbegin = reinterpret_cast<const char*>(packed) + wave * 4096 + lane * 16;
+    st.gend = st.gbegin + size_t(kChunks) * kChunkBytes;
+    st.gnext = st.gbegin;
+    st.smem = smem;
+    st.lds_base = __builtin_amdgcn_readfirstlane(
+        unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * 4096u);
+    st.pf_slot = 0;
+    st.rd_slot = kRing - 1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) in[i] = relu16(out[i]);
+    for (int i = 0; i < kRing - 1; ++i) ws_prefetch(st);
 
-    float sigma = 0.f;
-    for (int li = 1; li <= 8; ++li) {
-        if (li == 5) {
-            mfma_layer<8, 2, 8, 0>(ws, ring, bias_h + li * 256, pe, in, nullptr, out);
-            ws += kStepsSkip * 64;
+    for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+        const int64_t tile = tg * 4 + wave;
+        int64_t pidx = tile * 32 + j;
+        const bool valid = pidx < n_points;
+        if (!valid) pidx = n_points - 1;
+        float px, py, pz, dx, dy, dz;
+        if (rays_mode) {
+            const int64_t tile_c = pidx / 32;  // clamped tile for waves past the end
+            const int64_t ray = tile_c / tiles_per_ray;
+            const int s0 = int(tile_c - ray * tiles_per_ray) * 32;
+            const float ox = a0[ray * 3 + 0], oy = a0[ray * 3 + 1], oz = a0[ray * 3 + 2];
+            dx = a1[ray * 3 + 0], dy = a1[ray * 3 + 1], dz = a1[ray * 3 + 2];
+            // volume_renderer.py:230; torch-CPU's norm over 3 elements is this fma chain (bit-exact dhat
+            // matters: a 1-ulp change of the point moves the 2^9-band encoding by ~2e-4)
+            const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
+            const float zz = zbuf[ray * z_stride + s0 + (valid ? j : int(pidx & 31))];
+            px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231, separate mul and add like torch
+            py = __fadd_rn(oy, __fmul_rn(zz, dy));
+            pz = __fadd_rn(oz, __fmul_rn(zz, dz));
         } else {
-            mfma_layer<8, 0, 8, 0>(ws, ring, bias_h + li * 256, nullptr, in, nullptr, out);
-            ws += kStepsHidden * 64;
+            px = a0[pidx * 3 + 0], py = a0[pidx * 3 + 1], pz = a0[pidx * 3 + 2];
+            dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
         }
-        if (li == 8) {
-            // alpha_linear on h7 (still in `in`): VALU dot over this half's 128 features
-            const float* aw = packed + kOffAlphaW + h * 16;
-            float acc = 0.f;
+
+        f32x16 pe[2], dpe[1];
+        pe[0] = encode_block<10, 0>(px, py, pz, h);
+        pe[1] = encode_block<10, 1>(px, py, pz, h);
+        dpe[0] = encode_block<4, 0>(dx, dy, dz, h);
+
+        f32x16 A[8], B[8];
+        // <NOB, NPRE, NHID, NPOST, RELU, PEND_IN>: the last output block of a RELU layer is activated by its consumer
+        mfma_layer<8, 2, 0, 0, true, false>(st, lane, bias_h + 0 * 256, pe, nullptr, nullptr, A);  // pts_linears.0
+        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 1 * 256, nullptr, A, nullptr, B);
+        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 2 * 256, nullptr, B, nullptr, A);
+        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 3 * 256, nullptr, A, nullptr, B);
+        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 4 * 256, nullptr, B, nullptr, A);
+        mfma_layer<8, 2, 8, 0, true, true>(st, lane, bias_h + 5 * 256, pe, A, nullptr, B);         // skip: [pe, h]
+        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 6 * 256, nullptr, B, nullptr, A);
+        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 7 * 256, nullptr, A, nullptr, B);    // h7 in B
+        B[7] = relu16(B[7]);
+
+        // alpha_linear on h7: VALU dot over this half's 128 features
+        float sigma = 0.f;
+        {
+            const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {
                 const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
 #pragma unroll
-                for (int t = 0; t < 16; ++t) acc = fmaf(w[t], in[kb][t], acc);
-            }
-            sigma = acc;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) in[i] = out[i];  // feature_linear: no activation
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) in[i] = relu16(out[i]);
-        }
-    }
-
-    // views_linears.0 on cat([feature, dir PE]) -> 128, relu
-    mfma_layer<4, 0, 8, 1>(ws, ring, bias_h + 9 * 256, nullptr, in, dpe, out);
-    float r = 0.f, g = 0.f, b = 0.f;
-    {
-        const float* rw = packed + kOffRgbW + h * 16;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const f32x16 hv = relu16(out[kb]);
-            const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
-            const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
-            const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                r = fmaf(w0[t], hv[t], r);
-                g = fmaf(w1[t], hv[t], g);
-                b = fmaf(w2[t], hv[t], b);
+                for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], B[kb][t], sigma);
             }
         }
+        mfma_layer<8, 0, 8, 0, false, false>(st, lane, bias_h + 8 * 256, nullptr, B, nullptr, A);  // feature_linear
+        mfma_layer<4, 0, 8, 1, true, false>(st, lane, bias_h + 9 * 256, nullptr, A, dpe, B);       // views_linears.0
+        B[3] = relu16(B[3]);
+        float r = 0.f, g = 0.f, b = 0.f;
+        {
+            const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
+                const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
+                const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    r = fmaf(w0[t], B[kb][t], r);
+                    g = fmaf(w1[t], B[kb][t], g);
+                    b = fmaf(w2[t], B[kb][t], b);
+                }
+            }
+        }
+        // combine the two lane halves (each holds half of every dot product)
+        r += __shfl_xor(r, 32);
+        g += __shfl_xor(g, 32);
+        b += __shfl_xor(b, 32);
+        sigma += __shfl_xor(sigma, 32);
+        if (h == 0 && valid) {
+            const float* rb = cst + (kOffRgbB - kOffBias);
+            raw[pidx] = make_float4(r + rb[0], g + rb[1], b + rb[2], sigma + cst[kOffAlphaB - kOffBias]);
+        }
     }
-    // combine the two lane halves (each holds half of every dot product)
-    r += __shfl_xor(r, 32);
-    g += __shfl_xor(g, 32);
-    b += __shfl_xor(b, 32);
-    sigma += __shfl_xor(sigma, 32);
-    if (h == 0 && valid) {
-        const float4 rb = *reinterpret_cast<const float4*>(packed + kOffRgbB);
-        const float ab = packed[kOffAlphaB];
-        raw[pidx] = make_float4(r + rb.x, g + rb.y, b + rb.z, sigma + ab);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
 
-static int check_common(const float* packed, const void* a, const void* b, const void* raw) {
+int launch_mlp(const float* packed, const float* a0, const float* a1, const float* z, int64_t z_stride,
+               int tiles_per_ray, int rays_mode, int64_t n_points, float* raw, hipStream_t stream) {
+    const int64_t tiles = (n_points + 31) / 32;
+    const int64_t groups = (tiles + 3) / 4;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    const unsigned grid = unsigned(groups < cus ? groups : cus);
+    nrf_launch_begin();
+    mlp_fwd_kernel<<<dim3(grid), 256, 0, stream>>>(packed, a0, a1, z, z_stride, tiles_per_ray, rays_mode, n_points,
+                                                   groups, reinterpret_cast<float4*>(raw));
+    return nrf_launch_status();
+}
+
+int check_common(const float* packed, const void* a, const void* b, const void* raw) {
     if (!packed || !a || !b || !raw) return NRF_ERR_NULL;
     if (!nrf_aligned16(packed) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
     return NRF_OK;
 }
+
+}  // namespace
 
 NRF_EXPORT int nrf_mlp_forward_rays(const float* packed, const float* rays_o, const float* rays_d, const float* z,
                                     int64_t z_stride, int64_t n_rays, int n_samples, float* raw,
@@ -347,26 +460,15 @@ NRF_EXPORT int nrf_mlp_forward_rays(const float* packed, const float* rays_o, co
     if (n_rays == 0) return NRF_OK;  // empty batch: nothing to read or write, pointers may be NULL
     if (int st = check_common(packed, rays_o, rays_d, raw)) return st;
     if (!z) return NRF_ERR_NULL;
-    const int tiles_per_ray = n_samples / 32;
-    const int64_t tiles = n_rays * tiles_per_ray;
-    const int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
-    nrf_launch_begin();
-    mlp_fwd_kernel<true><<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        packed, rays_o, rays_d, z, z_stride, tiles_per_ray, tiles * 32, reinterpret_cast<float4*>(raw));
-    return nrf_launch_status();
+    if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
+    return launch_mlp(packed, rays_o, rays_d, z, z_stride, n_samples / 32, 1, n_rays * n_samples, raw,
+                      static_cast<hipStream_t>(stream));
 }
 
 NRF_EXPORT int nrf_mlp_forward_points(const float* packed, const float* pts, const float* dirs, int64_t n_points,
                                       float* raw, nrf_stream_t stream) {
-    if (n_points < 0) return NRF_ERR_SHAPE;
+    if (n_points < 0 || n_points > (int64_t(1) << 40)) return NRF_ERR_SHAPE;
     if (n_points == 0) return NRF_OK;
     if (int st = check_common(packed, pts, dirs, raw)) return st;
-    const int64_t tiles = (n_points + 31) / 32;
-    const int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
-    nrf_launch_begin();
-    mlp_fwd_kernel<false><<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        packed, pts, dirs, nullptr, 0, 1, n_points, reinterpret_cast<float4*>(raw));
-    return nrf_launch_status();
+    return launch_mlp(packed, pts, dirs, nullptr, 0, 1, 0, n_points, raw, static_cast<hipStream_t>(stream));
 }
