@@ -116,9 +116,13 @@ NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, fl
     // pts_linears.0: 63 PE -> 256
     launch(PackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0}, 0);
     for (int l = 1; l <= 7; ++l) {
-        if (l == 5)  // network.py:58 cat([input_pts, h]): PE columns first, then the 256 hidden
-            launch(PackLayer{w[5], nullptr, 319, 8, 2, 8, 0, 10, 0, 0, 63, 0}, 5);
-        else
+        if (l == 5) {
+            // network.py:58 cat([input_pts, h]): source columns 0..62 are the PE, 63..318 the hidden.  Streamed as
+            // a plain 256->256 layer (so it shares the hidden-layer code) followed by a PE pass that accumulates.
+            launch(PackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0}, 5);
+            PackLayer pe_part{w[5], packed + int64_t(kLayerStep[5] + kStepsHidden) * kStepFloats, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0};
+            pack_layer_kernel<<<(kStepsL0 * kStepFloats + 255) / 256, 256, 0, stream>>>(pe_part);
+        } else
             launch(PackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, l);
     }
     launch(PackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, 8);  // feature_linear
@@ -169,12 +173,14 @@ struct WeightStream {
     unsigned lds_base;  // LDS byte address of smem + wave * 4 KiB (this wave fills pieces 4w..4w+3)
     char* smem;
     int pf_slot, rd_slot;
+    const float4* rd;   // this lane's float4 of step 0 of the chunk being read
+    float4 w;           // weights of the next step to be multiplied (already read from LDS)
 };
 
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0 + 1 KiB).
 // Inline asm on purpose: hipcc's waitcnt pass orders every ds_read behind ALL outstanding
 // LDS-DMA it knows of (s_waitcnt vmcnt(0)), which would serialise the ring; issued from asm the
-// loads are invisible to it and are ordered by ws_next_chunk's counted vmcnt + barrier instead.
+// loads are invisible to it and are ordered by ws_acquire's counted vmcnt + barrier instead.
 __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
@@ -188,10 +194,12 @@ __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-__device__ __forceinline__ void ws_prefetch(WeightStream& st) {
-    const unsigned l = st.lds_base + unsigned(st.pf_slot) * kChunkBytes;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(st.gnext + j * 1024, l + j * 1024);
+// piece j (0..3) of this wave's share of the chunk being prefetched
+__device__ __forceinline__ void ws_prefetch_piece(const WeightStream& st, int j) {
+    glds16(st.gnext + j * 1024, st.lds_base + unsigned(st.pf_slot) * kChunkBytes + j * 1024);
+}
+
+__device__ __forceinline__ void ws_prefetch_advance(WeightStream& st) {
     const char* nx = st.gnext + kChunkBytes;
     st.gnext = nx == st.gend ? st.gbegin : nx;
     // keep the address a run-time value: the schedule repeats every tile, and LICM would otherwise
@@ -202,13 +210,13 @@ __device__ __forceinline__ void ws_prefetch(WeightStream& st) {
 
 // Make the next chunk readable: my own 4 pieces of it have landed once at most 4*(kRing-2)
 // younger VMEM ops are outstanding; the barrier then covers the other waves' pieces and also
-// says every wave is done reading the previous chunk, whose slot is refilled right away.
-__device__ __forceinline__ const float4* ws_next_chunk(WeightStream& st, int lane) {
+// says every wave is done reading the previous chunk, whose slot the caller refills right away
+// (ws_prefetch_piece x4 + ws_prefetch_advance, spread between MFMAs).
+__device__ __forceinline__ void ws_acquire(WeightStream& st, int lane) {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(4 * (kRing - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
-    ws_prefetch(st);
     st.rd_slot = st.rd_slot + 1 == kRing ? 0 : st.rd_slot + 1;
-    return reinterpret_cast<const float4*>(st.smem + st.rd_slot * kChunkBytes) + lane;
+    st.rd = reinterpret_cast<const float4*>(st.smem + st.rd_slot * kChunkBytes) + lane;
 }
 
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
@@ -222,46 +230,47 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
     return r;
 }
 
-// One GEMM layer of the chain for this wave's 32 points: out[ob] = act(bias + sum_k W . kin).
-// Layers ping-pong between two register sets, nothing is copied.  The activation of output
-// block ob is applied in place AFTER the first MFMAs of block ob+1 have been issued, so the VALU
-// work runs under the matrix pipe; the last block's activation is left to the consumer
-// (PEND_IN: relu hid[NHID-1] the same way at the start of the next layer).
-template <int NOB, int NPRE, int NHID, int NPOST, bool RELU, bool PEND_IN>
+// One GEMM layer of the chain for this wave's 32 points: Y[ob] = bias + sum_k W . [pre, X, post]
+// where X = act(Y of the previous layer).  Y holds raw (pre-activation) outputs; the activated
+// copy X[i] = act(Y[i]) is made just in time while output block 0 is being accumulated (block i
+// of Y is not overwritten before output block i starts, X[0] is made before Y[0] is
+// re-initialised), so the VALU work runs under the matrix pipe and every layer has the same
+// X -> Y orientation: identical layers share one unrolled body inside a run-time loop and the
+// whole kernel (3136 unrolled MFMAs, ~45 KB of code) stays inside the 64 KB instruction cache.
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_COPY = 2 };
+template <int NOB, int NPRE, int NHID, int NPOST, int ACT, bool ACCUM = false>
 __device__ __forceinline__ void mfma_layer(WeightStream& st, int lane, const float* bias_h, const f32x16* pre,
-                                           f32x16* hid, const f32x16* post, f32x16* out) {
+                                           f32x16* X, const f32x16* post, f32x16* Y) {
     constexpr int NKB = NPRE + NHID + NPOST;
     constexpr int NS = NOB * NKB * 4;
     static_assert(NS % kChunkSteps == 0, "layer must be a whole number of chunks");
-    static_assert(!PEND_IN || NPRE + NHID > 1, "the pending block must not be the first one consumed");
     // The weights of step s+1 are read from LDS before the MFMAs of step s are issued (the read
-    // latency hides under 256 matrix-core cycles); the ring hand-over for the next chunk is done
-    // ahead of a chunk's LAST step for the same reason.
-    const float4* rd = ws_next_chunk(st, lane);
-    float4 w = rd[0];
+    // latency hides under 256 matrix-core cycles).  The ring hand-over to the next chunk -- also
+    // the next layer's or next tile's first chunk -- happens ahead of a chunk's LAST step, and
+    // the 4 LDS-DMA issues that refill the freed slot go one into each MFMA gap of that step.
+    if (NHID > 0) X[0] = ACT == ACT_RELU ? relu16(Y[0]) : Y[0];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
-        out[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+        if (!ACCUM) Y[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const f32x16 x = kb < NPRE ? pre[kb] : (kb < NPRE + NHID ? hid[kb - NPRE] : post[kb - NPRE - NHID]);
+            if (ob == 0 && kb > NPRE && kb < NPRE + NHID) X[kb - NPRE] = ACT == ACT_RELU ? relu16(Y[kb - NPRE]) : Y[kb - NPRE];
+            const f32x16 x = kb < NPRE ? pre[kb] : (kb < NPRE + NHID ? X[kb - NPRE] : post[kb - NPRE - NHID]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int s = (ob * NKB + kb) * 4 + q;
-                float4 wn = w;
-                if (s + 1 < NS) {
-                    if ((s + 1) % kChunkSteps == 0) rd = ws_next_chunk(st, lane);
-                    wn = rd[((s + 1) % kChunkSteps) * 64];
-                }
-                out[ob] = NRF_MFMA(w.x, x[4 * q + 0], out[ob]);
-                out[ob] = NRF_MFMA(w.y, x[4 * q + 1], out[ob]);
-                out[ob] = NRF_MFMA(w.z, x[4 * q + 2], out[ob]);
-                out[ob] = NRF_MFMA(w.w, x[4 * q + 3], out[ob]);
-                w = wn;
-                if (kb == 0 && q == 0) {  // deferred activations, now covered by the MFMAs just issued
-                    if (RELU && ob > 0) out[ob - 1] = relu16(out[ob - 1]);
-                    if (PEND_IN && ob == 0) hid[NHID - 1] = relu16(hid[NHID - 1]);
-                }
+                const bool hand = (s + 1) % kChunkSteps == 0;
+                const float4 w = st.w;
+                if (hand) ws_acquire(st, lane);
+                st.w = st.rd[((s + 1) % kChunkSteps) * 64];
+                Y[ob] = NRF_MFMA(w.x, x[4 * q + 0], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 0); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA(w.y, x[4 * q + 1], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 1); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA(w.z, x[4 * q + 2], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 2); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA(w.w, x[4 * q + 3], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 3); ws_prefetch_advance(st); __builtin_amdgcn_sched_barrier(0); }
             }
         }
     }
@@ -343,7 +352,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict
     st.pf_slot = 0;
     st.rd_slot = kRing - 1;
 #pragma unroll
-    for (int i = 0; i < kRing - 1; ++i) ws_prefetch(st);
+    for (int i = 0; i < kRing; ++i) {  // fill the whole ring, then take chunk 0
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ws_prefetch_piece(st, jj);
+        ws_prefetch_advance(st);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRing - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = 0;
+    st.rd = reinterpret_cast<const float4*>(smem) + lane;
+    st.w = st.rd[0];
 
     for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
         const int64_t tile = tg * 4 + wave;
@@ -375,19 +393,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict
         pe[1] = encode_block<10, 1>(px, py, pz, h);
         dpe[0] = encode_block<4, 0>(dx, dy, dz, h);
 
-        f32x16 A[8], B[8];
-        // <NOB, NPRE, NHID, NPOST, RELU, PEND_IN>: the last output block of a RELU layer is activated by its consumer
-        mfma_layer<8, 2, 0, 0, true, false>(st, lane, bias_h + 0 * 256, pe, nullptr, nullptr, A);  // pts_linears.0
-        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 1 * 256, nullptr, A, nullptr, B);
-        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 2 * 256, nullptr, B, nullptr, A);
-        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 3 * 256, nullptr, A, nullptr, B);
-        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 4 * 256, nullptr, B, nullptr, A);
-        mfma_layer<8, 2, 8, 0, true, true>(st, lane, bias_h + 5 * 256, pe, A, nullptr, B);         // skip: [pe, h]
-        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 6 * 256, nullptr, B, nullptr, A);
-        mfma_layer<8, 0, 8, 0, true, true>(st, lane, bias_h + 7 * 256, nullptr, A, nullptr, B);    // h7 in B
-        B[7] = relu16(B[7]);
-
-        // alpha_linear on h7: VALU dot over this half's 128 features
+        f32x16 X[8], Y[8];
+        mfma_layer<8, 2, 0, 0, ACT_NONE>(st, lane, bias_h, pe, X, nullptr, Y);               // pts_linears.0
+        for (int li = 1; li <= 8; ++li) {                                                     // pts 1..7, feature
+            mfma_layer<8, 0, 8, 0, ACT_RELU>(st, lane, bias_h + li * 256, nullptr, X, nullptr, Y);
+            if (li == 5)  // skip: cat([pe, h]) (network.py:58) = the hidden part above + this PE pass on top
+                mfma_layer<8, 2, 0, 0, ACT_NONE, true>(st, lane, nullptr, pe, X, nullptr, Y);
+        }
+        // X = relu(h7) (made while feature_linear ran): alpha_linear as a VALU dot over this half's 128 features
         float sigma = 0.f;
         {
             const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
@@ -395,25 +408,25 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict
             for (int kb = 0; kb < 8; ++kb) {
                 const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
 #pragma unroll
-                for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], B[kb][t], sigma);
+                for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], X[kb][t], sigma);
             }
         }
-        mfma_layer<8, 0, 8, 0, false, false>(st, lane, bias_h + 8 * 256, nullptr, B, nullptr, A);  // feature_linear
-        mfma_layer<4, 0, 8, 1, true, false>(st, lane, bias_h + 9 * 256, nullptr, A, dpe, B);       // views_linears.0
-        B[3] = relu16(B[3]);
+        // views_linears.0 on cat([feature (no activation), dir PE]) -> 128
+        mfma_layer<4, 0, 8, 1, ACT_COPY>(st, lane, bias_h + 9 * 256, nullptr, X, dpe, Y);
         float r = 0.f, g = 0.f, b = 0.f;
         {
             const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
+                const f32x16 hv = relu16(Y[kb]);
                 const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
                 const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
                 const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
-                    r = fmaf(w0[t], B[kb][t], r);
-                    g = fmaf(w1[t], B[kb][t], g);
-                    b = fmaf(w2[t], B[kb][t], b);
+                    r = fmaf(w0[t], hv[t], r);
+                    g = fmaf(w1[t], hv[t], g);
+                    b = fmaf(w2[t], hv[t], b);
                 }
             }
         }
