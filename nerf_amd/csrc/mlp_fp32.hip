@@ -153,9 +153,15 @@ namespace {
 // chunks ahead of use, one raw s_barrier per chunk and a COUNTED vmcnt so the prefetches stay in
 // flight across it.  The kernel is persistent (one workgroup per CU) and the stream wraps, so
 // the ring never drains between tiles.  Every layer is a whole number of chunks.
-constexpr int kChunkSteps = 16;
+#ifndef NRF_CHUNK_STEPS
+#define NRF_CHUNK_STEPS 16
+#endif
+#ifndef NRF_RING
+#define NRF_RING 5
+#endif
+constexpr int kChunkSteps = NRF_CHUNK_STEPS;
 constexpr int kChunkBytes = kChunkSteps * kStepFloats * 4;  // 16 KiB
-constexpr int kRing = 5;
+constexpr int kRing = NRF_RING;
 constexpr int kChunks = kStreamSteps / kChunkSteps;  // 145
 static_assert(kStreamSteps % kChunkSteps == 0, "layers must be chunk aligned");
 static_assert(kStepsL0 % kChunkSteps == 0 && kStepsHidden % kChunkSteps == 0 && kStepsSkip % kChunkSteps == 0 &&
@@ -182,6 +188,7 @@ struct WeightStream {
 // LDS-DMA it knows of (s_waitcnt vmcnt(0)), which would serialise the ring; issued from asm the
 // loads are invisible to it and are ordered by ws_acquire's counted vmcnt + barrier instead.
 __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
+#ifdef NRF_GLDS_SAVE_M0
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -192,10 +199,24 @@ __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_dst)
         : "memory");
+#else
+    // M0 is not saved/restored: nothing else in this kernel uses it (checked in the .s: the only
+    // m0 writes are these), and the restore would have to wait for the DMA to consume M0.
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+#endif
 }
 
 // piece j (0..3) of this wave's share of the chunk being prefetched
 __device__ __forceinline__ void ws_prefetch_piece(const WeightStream& st, int j) {
+#if defined(NRF_ABLATE_NOSYNC) || defined(NRF_ABLATE_NOGLDS)  // diagnostic builds only (tools/ubench/mlp_ablate.hip): results are wrong
+    return;
+#endif
     glds16(st.gnext + j * 1024, st.lds_base + unsigned(st.pf_slot) * kChunkBytes + j * 1024);
 }
 
@@ -213,8 +234,10 @@ __device__ __forceinline__ void ws_prefetch_advance(WeightStream& st) {
 // says every wave is done reading the previous chunk, whose slot the caller refills right away
 // (ws_prefetch_piece x4 + ws_prefetch_advance, spread between MFMAs).
 __device__ __forceinline__ void ws_acquire(WeightStream& st, int lane) {
+#if !defined(NRF_ABLATE_NOSYNC) && !defined(NRF_ABLATE_NOBARRIER)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(4 * (kRing - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
+#endif
     st.rd_slot = st.rd_slot + 1 == kRing ? 0 : st.rd_slot + 1;
     st.rd = reinterpret_cast<const float4*>(st.smem + st.rd_slot * kChunkBytes) + lane;
 }
@@ -248,13 +271,18 @@ __device__ __forceinline__ void mfma_layer(WeightStream& st, int lane, const flo
     // latency hides under 256 matrix-core cycles).  The ring hand-over to the next chunk -- also
     // the next layer's or next tile's first chunk -- happens ahead of a chunk's LAST step, and
     // the 4 LDS-DMA issues that refill the freed slot go one into each MFMA gap of that step.
-    if (NHID > 0) X[0] = ACT == ACT_RELU ? relu16(Y[0]) : Y[0];
+#ifdef NRF_ABLATE_NOACT
+#define NRF_ACT(v) (v)
+#else
+#define NRF_ACT(v) (ACT == ACT_RELU ? relu16(v) : (v))
+#endif
+    if (NHID > 0) X[0] = NRF_ACT(Y[0]);
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         if (!ACCUM) Y[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (ob == 0 && kb > NPRE && kb < NPRE + NHID) X[kb - NPRE] = ACT == ACT_RELU ? relu16(Y[kb - NPRE]) : Y[kb - NPRE];
+            if (ob == 0 && kb > NPRE && kb < NPRE + NHID) X[kb - NPRE] = NRF_ACT(Y[kb - NPRE]);
             const f32x16 x = kb < NPRE ? pre[kb] : (kb < NPRE + NHID ? X[kb - NPRE] : post[kb - NPRE - NHID]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -262,7 +290,9 @@ __device__ __forceinline__ void mfma_layer(WeightStream& st, int lane, const flo
                 const bool hand = (s + 1) % kChunkSteps == 0;
                 const float4 w = st.w;
                 if (hand) ws_acquire(st, lane);
+#ifndef NRF_ABLATE_NOLDS
                 st.w = st.rd[((s + 1) % kChunkSteps) * 64];
+#endif
                 Y[ob] = NRF_MFMA(w.x, x[4 * q + 0], Y[ob]);
                 if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 0); __builtin_amdgcn_sched_barrier(0); }
                 Y[ob] = NRF_MFMA(w.y, x[4 * q + 1], Y[ob]);
@@ -305,7 +335,11 @@ __device__ __forceinline__ f32x16 encode_block(float x, float y, float z, int h)
         float v;
         if (n < 3 * L) {
             const float c = (n % 3) == 0 ? x : ((n % 3) == 1 ? y : z);
+#ifdef NRF_ABLATE_NOPE
+            v = c * float(1 << (n / 3)) + h;
+#else
             v = sin_or_cos(c * float(1 << (n / 3)), h);
+#endif
         } else if (n == 3 * L) {
             v = h ? y : x;
         } else if (n == 3 * L + 1) {
