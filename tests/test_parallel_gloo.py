@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: 2 ranks over gloo assemble one frame from ray shards (no GPU needed)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nerf_amd.parallel import render_frame_sharded, shard_range, view_schedule
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 640000, 640001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_view_schedule_round_robin():
+    items = [view_schedule(200, r, 8, tiles_per_view=2) for r in range(8)]
+    assert sorted(sum(items, [])) == [(v, t) for v in range(200) for t in range(2)]
+    assert max(map(len, items)) - min(map(len, items)) <= 1
+
+
+def _fake_render(first, count):
+    i = torch.arange(first, first + count, dtype=torch.float32)
+    return {"fine_rgb_map": torch.stack([i, 2 * i, 3 * i], -1), "fine_depth_map": i * 0.5,
+            "alpha_map": (i % 7)[:, None]}
+
+
+def _worker(rank, world, port, n_rays, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out, span = render_frame_sharded(_fake_render, n_rays, rank, world, gather=True)
+        ref = _fake_render(0, n_rays)
+        ok = all(torch.equal(out[k], ref[k]) for k in ref) and span == shard_range(n_rays, rank, world)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rays", [1001, 64])
+def test_two_rank_frame_assembly(n_rays):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n_rays) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rays, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
