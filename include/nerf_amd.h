@@ -112,6 +112,40 @@ int nrf_sample_fine(const float* weights, const float* bins, int64_t bins_stride
                     int n_coarse, int n_importance, float* z_out, float* fine_out, int32_t* idx_out,
                     nrf_stream_t stream);
 
+/* ---- training step: backward kernels (what autograd does for loss.backward(), -------- */
+/* ---- src/train/trainers/trainer.py:73, through the reference's torch ops) ----------- */
+
+/* Number of floats of the transposed weight stream the backward chain reads. */
+int64_t nrf_packed_bwd_floats(void);
+/* W^T of views(:, :256), feature, pts7..pts1 in MFMA streaming order (see nrf_pack_weights). */
+int nrf_pack_weights_transposed(const float* const* w_host, float* packed_t, nrf_stream_t stream);
+
+/* Saved tensors of the training forward, sized for n_rays * n_samples points (whole 4-tile groups). */
+int64_t nrf_mlp_train_tiles(int64_t n_rays, int n_samples);
+int64_t nrf_mlp_acts_bytes(int64_t n_rays, int n_samples);
+int64_t nrf_mlp_masks_bytes(int64_t n_rays, int n_samples);
+/* nrf_mlp_forward_rays that also saves every layer's activated input (acts) and relu sign bits
+ * (masks) for nrf_mlp_backward. */
+int nrf_mlp_forward_rays_train(const float* packed, const float* rays_o, const float* rays_d, const float* z,
+                               int64_t z_stride, int64_t n_rays, int n_samples, float* raw, float* acts,
+                               uint32_t* masks, nrf_stream_t stream);
+
+/* d(raw) from d(rgb_map) (n_rays,3), d(depth_map) (n_rays,), d(acc_map) (n_rays,) -- any may be NULL:
+ * the backward of nrf_composite (volume_renderer.py:244-263 under autograd).  n_samples <= 512. */
+int nrf_composite_backward(const float* raw, const float* z, int64_t z_stride, int64_t n_rays, int n_samples,
+                           int white_bkgd, const float* grad_rgb, const float* grad_depth, const float* grad_acc,
+                           float* grad_raw, nrf_stream_t stream);
+
+/* Parameters of one model: 595,844.  grad_flat of nrf_mlp_backward has this many floats, laid out as the
+ * reference state dict: per layer (include order above) weight (out, in) row-major, then bias. */
+int64_t nrf_model_param_floats(void);
+int64_t nrf_mlp_backward_workspace_bytes(int64_t n_rays, int n_samples);
+/* Parameter gradients of one 8x256 MLP (network.py:49-74) from grad_raw (n_rays, n_samples, 4):
+ * dgrad chain on the matrix cores + per-layer wgrad GEMMs + bias sums; overwrites grad_flat. */
+int nrf_mlp_backward(const float* packed, const float* packed_t, const float* grad_raw, const float* acts,
+                     const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace, int64_t workspace_bytes,
+                     float* grad_flat, nrf_stream_t stream);
+
 /* ---- whole forward path: volume_renderer.py:143-153 (render_coarse + render_fine) --- */
 
 typedef struct nrf_render_args {

@@ -16,6 +16,9 @@ SYMBOLS = (
     "nrf_version", "nrf_strerror", "nrf_packed_floats", "nrf_pack_weights", "nrf_raygen",
     "nrf_perturb_samples", "nrf_mlp_forward_rays", "nrf_mlp_forward_points", "nrf_composite",
     "nrf_sample_fine", "nrf_render_workspace_bytes", "nrf_render",
+    "nrf_packed_bwd_floats", "nrf_pack_weights_transposed", "nrf_mlp_train_tiles", "nrf_mlp_acts_bytes",
+    "nrf_mlp_masks_bytes", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_model_param_floats",
+    "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward",
 )
 
 P = C.c_void_p
@@ -66,6 +69,17 @@ def lib() -> C.CDLL:
     L.nrf_render_workspace_bytes.restype = I64
     L.nrf_render_workspace_bytes.argtypes = [I64, INT, INT]
     L.nrf_render.argtypes = [C.POINTER(RenderArgs), P]
+    L.nrf_packed_bwd_floats.restype = I64
+    L.nrf_pack_weights_transposed.argtypes = [P, P, P]
+    for name in ("nrf_mlp_train_tiles", "nrf_mlp_acts_bytes", "nrf_mlp_masks_bytes", "nrf_mlp_backward_workspace_bytes"):
+        getattr(L, name).restype = I64
+        getattr(L, name).argtypes = [I64, INT]
+    L.nrf_model_param_floats.restype = I64
+    L.nrf_mlp_forward_rays_train.argtypes = [P, P, P, P, I64, I64, INT, P, P, P, P]
+    L.nrf_composite_backward.argtypes = [P, P, I64, I64, INT, INT, P, P, P, P, P]
+    L.nrf_mlp_backward.argtypes = [P, P, P, P, P, I64, INT, P, I64, P, P]
+    for name in ("nrf_pack_weights_transposed", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_mlp_backward"):
+        getattr(L, name).restype = INT
     for name in ("nrf_pack_weights", "nrf_raygen", "nrf_perturb_samples", "nrf_mlp_forward_rays",
                  "nrf_mlp_forward_points", "nrf_composite", "nrf_sample_fine", "nrf_render"):
         getattr(L, name).restype = INT

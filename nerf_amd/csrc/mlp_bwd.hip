@@ -1,0 +1,392 @@
+// Backward of the 8x256 NeRF MLP for the training step: parameter gradients from d(raw).
+//
+// Replaces what autograd does for network.py:49-74 inside `loss.backward()`
+// (src/train/trainers/trainer.py:73).  Three kinds of kernels:
+//
+//   dgrad  register-chained like the forward (mlp_chain.h): d(input of layer l) = W_l^T . dY_l on
+//          the fp32 matrix cores with the TRANSPOSED weight stream through the same LDS-DMA ring;
+//          relu' comes from the sign bits the training forward saved (4 words per lane and layer);
+//          every dY_l is written once to HBM in [tile][row][32 points] layout for the wgrad GEMMs.
+//          Inputs (points, directions) need no gradient, so the chain stops at layer 1's input.
+//   wgrad  dW_l = dY_l . X_l^T, a (256 x K) x P GEMM with the reduction over P points split across
+//          workgroups: each workgroup streams its slice of tiles through LDS (row stride 33: the
+//          operand reads have the FEATURE on the lane and are bank-conflict free), keeps the full
+//          256 x K partial in registers (4 waves x up to 320 accumulators), writes it once.
+//          Bias gradients (row sums of dY) ride along.
+//   reduce sums the per-slice partials and scatters into the flat gradient buffer in the
+//          reference's (out, in) state-dict layout, undoing the kernel's encoding-slot order.
+#include "mlp_chain.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// dgrad
+// ------------------------------------------------------------------------------------
+// X[i] = (Y[i] + dsig * w_alpha[i]) masked by the saved relu signs; stored as dY rows of the layer
+struct OpBwdMask {
+    float* dst;          // dys + (tile * kDyRows + first row) * 32 + 4 * h * 32 + point
+    unsigned m[4];       // sign bits of the layer's forward output, 16 per 32-row block
+    const float* aw;     // alpha weights [kb][h][t] in LDS (this lane-half's 16 at aw + kb*32)
+    float dsig;          // d(raw sigma) when the layer output also fed alpha_linear, else 0
+    __device__ __forceinline__ f32x16 operator()(int i, f32x16 y) {
+        const f32x16 w = *reinterpret_cast<const f32x16*>(aw + i * 32);
+        f32x16 v;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = fmaf(w[t], dsig, y[t]);
+        const f32x16 x = mask16(v, (m[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+        store_block(dst, i, x);
+        return x;
+    }
+};
+struct OpBwdCopy {  // no activation between feature_linear and views_linears: dY8 = d(feature)
+    float* dst;
+    __device__ __forceinline__ f32x16 operator()(int i, f32x16 y) {
+        store_block(dst, i, y);
+        return y;
+    }
+};
+
+constexpr int kBwdChunks = kBwdSteps / kChunkSteps;  // 136
+static_assert(kBwdSteps % kChunkSteps == 0, "backward layers must be chunk aligned");
+
+__global__ __launch_bounds__(256, 1) void mlp_dgrad_kernel(const float* __restrict__ packed,    // forward pack: heads
+                                                           const float* __restrict__ packed_t,  // transposed stream
+                                                           const float4* __restrict__ graw,     // (n_points, 4)
+                                                           const unsigned* __restrict__ masks, int64_t n_points,
+                                                           int64_t n_groups, float* __restrict__ dys) {
+    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    {
+        const float4* src = reinterpret_cast<const float4*>(packed + kOffBias);
+        float4* dst = reinterpret_cast<float4*>(smem + kLdsConstOff);
+        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* cst = reinterpret_cast<const float*>(smem + kLdsConstOff);
+    const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
+    const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
+
+    WeightStream st;
+    ws_start(st, reinterpret_cast<const char*>(packed_t), kBwdChunks, smem, wave, lane);
+
+    for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+        const int64_t tile = tg * 4 + wave;
+        int64_t pidx = tile * 32 + j;
+        const bool valid = pidx < n_points;
+        if (!valid) pidx = n_points - 1;
+        float4 g = graw[pidx];
+        if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned* mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+        float* drow = dys + tile * (int64_t(kDyRows) * 32) + 4 * h * 32 + j;
+        if (h == 0) {  // d(raw) as 4 rows for the head wgrad jobs
+            float* r = dys + tile * (int64_t(kDyRows) * 32) + kDyRaw * 32 + j;
+            r[0] = g.x, r[32] = g.y, r[64] = g.z, r[96] = g.w;
+        }
+
+        // rgb_linear^T on the VALU: dYv = relu'(hv) * (W_rgb^T . d rgb)
+        f32x16 P[4], X[8], Y[8];
+        {
+            const unsigned m0 = mrow[(8 * 4 + 0) * 64], m1 = mrow[(8 * 4 + 1) * 64];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
+                const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
+                const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
+                f32x16 v;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = fmaf(w2[t], g.z, fmaf(w1[t], g.y, w0[t] * g.x));
+                P[kb] = mask16(v, ((kb < 2 ? m0 : m1) >> (16 * (kb & 1))) & 0xffffu);
+                store_block(drow + kDyV * 32, kb, P[kb]);
+            }
+        }
+        OpCopy op_none;
+        // d feature = W_views[:, :256]^T . dYv
+        mfma_layer<8, 4, 0, 0, INIT_ZERO>(st, lane, nullptr, P, X, nullptr, Y, op_none);
+        {   // d h7 (through feature_linear) = W_feature^T . d feature
+            OpBwdCopy op{drow + kDyFeat * 32};
+            mfma_layer<8, 0, 8, 0, INIT_ZERO>(st, lane, nullptr, nullptr, X, nullptr, Y, op);
+        }
+        for (int l = 7; l >= 1; --l) {  // dY_l = relu'(h_l) * d h_l;  d h_{l-1} = W_l^T . dY_l
+            OpBwdMask op;
+            op.dst = drow + l * 256 * 32;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) op.m[w] = mrow[(l * 4 + w) * 64];
+            op.aw = aw;
+            op.dsig = l == 7 ? g.w : 0.f;  // h7 also feeds alpha_linear
+            mfma_layer<8, 0, 8, 0, INIT_ZERO>(st, lane, nullptr, nullptr, X, nullptr, Y, op);
+        }
+        {   // dY_0 = relu'(h_0) * d h_0 (the encoding needs no gradient: chain ends)
+            OpBwdMask op;
+            op.dst = drow;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) op.m[w] = mrow[w * 64];
+            op.aw = aw;
+            op.dsig = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) (void)op(i, Y[i]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------
+// wgrad
+// ------------------------------------------------------------------------------------
+struct WgradJob {
+    const float* a;      // dys: [tile][a_stride rows][32]
+    const float* x;      // acts: [tile][x_stride rows][32]
+    int a_stride, x_stride;
+    int a_row0, a_rows;  // first dY row, valid rows (zero-filled up to M)
+    int x_row0[2], x_rows[2];  // up to two row segments of X (K = sum, each a multiple of 32)
+    int64_t n_tiles;
+    int tiles_per_slice;
+    float* partial;      // [slice][M][K]
+    float* pbias;        // [slice][M]
+};
+
+constexpr int kLdsRow = 33;  // padded tile row: feature-on-lane operand reads hit 32 distinct banks
+
+// M = 32 * 4 * MB rows (waves split the row blocks), K = 32 * KB columns.
+template <int MB, int KB, bool HEAD>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob job) {
+    constexpr int M = HEAD ? 32 : 128 * MB;
+    constexpr int K = HEAD ? 128 * KB : 32 * KB;  // HEAD: one row block, waves split the column blocks
+    constexpr int NACC = MB * KB;
+    __shared__ float sA[M * kLdsRow];
+    __shared__ float sB[K * kLdsRow];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const int slice = blockIdx.x;
+    const int64_t t0 = int64_t(slice) * job.tiles_per_slice;
+    int64_t t1 = t0 + job.tiles_per_slice;
+    if (t1 > job.n_tiles) t1 = job.n_tiles;
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
+    float bsum = 0.f;  // thread tid < M: row sum of dY row tid
+
+    constexpr int A4 = M * 8, B4 = K * 8;  // float4 pieces per tile (32 floats = 8 float4 per row)
+    constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
+    float4 ra[NA], rb[NB];
+
+    auto load_tile = [&](int64_t tile) {
+        const float4* pa = reinterpret_cast<const float4*>(job.a + (tile * job.a_stride + job.a_row0) * 32);
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            const int p = tid + 256 * n;
+            ra[n] = (p < A4 && (p >> 3) < job.a_rows) ? pa[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* xb = job.x + tile * job.x_stride * 32;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int p = tid + 256 * n;
+            const int row = p >> 3;
+            if (p < B4) {
+                const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
+                rb[n] = reinterpret_cast<const float4*>(xb + src_row * 32)[p & 7];
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            const int p = tid + 256 * n;
+            if (p < A4) {
+                float* d = sA + (p >> 3) * kLdsRow + (p & 7) * 4;
+                d[0] = ra[n].x, d[1] = ra[n].y, d[2] = ra[n].z, d[3] = ra[n].w;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int p = tid + 256 * n;
+            if (p < B4) {
+                float* d = sB + (p >> 3) * kLdsRow + (p & 7) * 4;
+                d[0] = rb[n].x, d[1] = rb[n].y, d[2] = rb[n].z, d[3] = rb[n].w;
+            }
+        }
+    };
+
+    if (t0 < t1) load_tile(t0);
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        __syncthreads();  // everyone is done reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t1) load_tile(tile + 1);  // in flight under the MFMAs below
+        if (tid < M) {
+            const float* r = sA + tid * kLdsRow;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) bsum += r[p];
+        }
+        const float* pa = sA + ((HEAD ? 0 : wave * MB * 32) + i) * kLdsRow + kh;
+        const float* pb = sB + ((HEAD ? wave * KB * 32 : 0) + i) * kLdsRow + kh;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {  // 2 points per MFMA
+            float av[MB], bv[KB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) av[m] = pa[m * 32 * kLdsRow + 2 * s];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) bv[k] = pb[k * 32 * kLdsRow + 2 * s];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int k = 0; k < KB; ++k) acc[m * KB + k] = NRF_MFMA(av[m], bv[k], acc[m * KB + k]);
+        }
+    }
+    // partial[slice][row][col]: 128 B contiguous per half-wave store
+    float* out = job.partial + int64_t(slice) * M * K;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int rb0 = HEAD ? 0 : (wave * MB + m) * 32;
+            const int cb0 = HEAD ? (wave * KB + k) * 32 : k * 32;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) out[int64_t(rb0 + acc_row(t, kh)) * K + cb0 + i] = acc[m * KB + k][t];
+        }
+    if (tid < M) job.pbias[int64_t(slice) * M + tid] = bsum;
+}
+
+// Column c of a wgrad job's K axis -> column of the reference weight matrix (or -1: padding).
+struct ColMap {
+    int seg_cols[2];   // columns of each X segment
+    int seg_kind[2];   // 0: hidden (identity), L > 0: encoding with L frequencies in kernel slot order
+    int seg_col0[2];   // first reference column of the segment
+};
+
+__device__ __forceinline__ int map_col(const ColMap& cm, int c) {
+    int seg = 0;
+    if (c >= cm.seg_cols[0]) { c -= cm.seg_cols[0]; seg = 1; }
+    if (cm.seg_kind[seg] == 0) return cm.seg_col0[seg] + c;
+    // encoding rows are saved at row 32*kb + acc_row(t, h): invert to slot n = 16*kb + t and half h
+    const int kb = c >> 5, r = c & 31;
+    const int h = (r >> 2) & 1, t = (r & 3) + 4 * (r >> 3);
+    const int col = pe_col(kb * 16 + t, h, cm.seg_kind[seg]);
+    return col < 0 ? -1 : cm.seg_col0[seg] + col;
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ pbias, int n_slices,
+                                    int M, int K, int m_valid, ColMap cm, float* __restrict__ gw, int ldw,
+                                    float* __restrict__ gb) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < M * K) {
+        const int m = idx / K, c = idx - m * K;
+        const int col = map_col(cm, c);
+        if (m < m_valid && col >= 0) {
+            float s = 0.f;
+            for (int sl = 0; sl < n_slices; ++sl) s += partial[int64_t(sl) * M * K + idx];
+            gw[int64_t(m) * ldw + col] = s;
+        }
+    }
+    if (idx < m_valid) {
+        float s = 0.f;
+        for (int sl = 0; sl < n_slices; ++sl) s += pbias[int64_t(sl) * M + idx];
+        gb[idx] = s;
+    }
+}
+
+}  // namespace
+
+// flat gradient layout of one model: the reference's state-dict order (include/nerf_amd.h layer
+// order), each layer weight (out, in) row-major followed by its bias
+static const int kLayerOut[12] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 1, 128, 3};
+static const int kLayerIn[12] = {63, 256, 256, 256, 256, 319, 256, 256, 256, 256, 283, 128};
+
+NRF_EXPORT int64_t nrf_model_param_floats(void) {
+    int64_t n = 0;
+    for (int l = 0; l < 12; ++l) n += int64_t(kLayerOut[l]) * kLayerIn[l] + kLayerOut[l];
+    return n;  // 595,844
+}
+
+NRF_EXPORT int64_t nrf_mlp_dys_bytes(int64_t n_rays, int n_samples) {
+    const int64_t t = nrf_mlp_train_tiles(n_rays, n_samples);
+    return t < 0 ? t : t * int64_t(kDyRows) * 32 * 4;
+}
+
+static int wgrad_slices(int64_t n_tiles) { return int(n_tiles < 256 ? n_tiles : 256); }
+
+NRF_EXPORT int64_t nrf_mlp_backward_workspace_bytes(int64_t n_rays, int n_samples) {
+    const int64_t t = nrf_mlp_train_tiles(n_rays, n_samples);
+    if (t < 0) return t;
+    const int64_t slices = wgrad_slices(t);
+    return nrf_mlp_dys_bytes(n_rays, n_samples) + slices * (256 * 320 + 256) * 4;
+}
+
+NRF_EXPORT int nrf_mlp_backward(const float* packed, const float* packed_t, const float* grad_raw, const float* acts,
+                                const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
+                                int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream_) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0) return NRF_ERR_SHAPE;
+    if (!packed || !packed_t || !grad_raw || !acts || !masks || !workspace || !grad_flat) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(packed_t) || !nrf_aligned16(grad_raw) || !nrf_aligned16(workspace) ||
+        !nrf_aligned16(acts))
+        return NRF_ERR_ALIGN;
+    if (workspace_bytes < nrf_mlp_backward_workspace_bytes(n_rays, n_samples)) return NRF_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t n_points = n_rays * n_samples;
+    const int64_t n_tiles = n_points / 32;
+    if (n_tiles == 0) return NRF_OK;
+    const int64_t groups = (n_tiles + 3) / 4;
+    float* dys = static_cast<float*>(workspace);
+    float* partial = dys + nrf_mlp_dys_bytes(n_rays, n_samples) / 4;
+    const int slices = wgrad_slices(n_tiles);
+    float* pbias = partial + int64_t(slices) * 256 * 320;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    nrf_launch_begin();
+    mlp_dgrad_kernel<<<dim3(unsigned(groups < cus ? groups : cus)), 256, 0, stream>>>(
+        packed, packed_t, reinterpret_cast<const float4*>(grad_raw), masks, n_points, groups, dys);
+
+    // offsets of each layer inside grad_flat
+    int64_t woff[12], boff[12], o = 0;
+    for (int l = 0; l < 12; ++l) {
+        woff[l] = o;
+        o += int64_t(kLayerOut[l]) * kLayerIn[l];
+        boff[l] = o;
+        o += kLayerOut[l];
+    }
+    const int tps = int((n_tiles + slices - 1) / slices);
+    auto job = [&](int a_row0, int a_rows, int xr0, int xn0, int xr1, int xn1) {
+        WgradJob j;
+        j.a = dys, j.x = acts, j.a_stride = kDyRows, j.x_stride = kActRows;
+        j.a_row0 = a_row0, j.a_rows = a_rows;
+        j.x_row0[0] = xr0, j.x_rows[0] = xn0, j.x_row0[1] = xr1, j.x_rows[1] = xn1;
+        j.n_tiles = n_tiles, j.tiles_per_slice = tps, j.partial = partial, j.pbias = pbias;
+        return j;
+    };
+    auto reduce = [&](int M, int K, int m_valid, ColMap cm, int layer) {
+        const int total = M * K;
+        wgrad_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(partial, pbias, slices, M, K, m_valid, cm,
+                                                                     grad_flat + woff[layer], kLayerIn[layer],
+                                                                     grad_flat + boff[layer]);
+    };
+    const dim3 grid(slices);
+    // pts_linears.0: dY0 x encoding
+    wgrad_kernel<2, 2, false><<<grid, 256, 0, stream>>>(job(0, 256, kActPe, 64, 0, 0));
+    reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 0);
+    for (int l = 1; l <= 7; ++l) {
+        if (l == 5) {  // cat([encoding, h4]) (network.py:58)
+            wgrad_kernel<2, 10, false><<<grid, 256, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
+            reduce(256, 320, 256, ColMap{{64, 256}, {10, 0}, {0, 63}}, 5);
+        } else {
+            wgrad_kernel<2, 8, false><<<grid, 256, 0, stream>>>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0));
+            reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, l);
+        }
+    }
+    // feature_linear: d feature x h7
+    wgrad_kernel<2, 8, false><<<grid, 256, 0, stream>>>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0));
+    reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, 8);
+    // views_linears.0: dYv x cat([feature, dir encoding]) (network.py:63)
+    wgrad_kernel<1, 9, false><<<grid, 256, 0, stream>>>(job(kDyV, 128, kActFeat, 256, kActDpe, 32));
+    reduce(128, 288, 128, ColMap{{256, 32}, {0, 4}, {0, 256}}, 10);
+    // alpha_linear: d sigma (raw row 3) x h7;  rgb_linear: d rgb (raw rows 0..2) x hv
+    wgrad_kernel<1, 2, true><<<grid, 256, 0, stream>>>(job(kDyRaw + 3, 1, kActH + 7 * 256, 256, 0, 0));
+    reduce(32, 256, 1, ColMap{{256, 0}, {0, 0}, {0, 0}}, 9);
+    wgrad_kernel<1, 1, true><<<grid, 256, 0, stream>>>(job(kDyRaw, 3, kActHv, 128, 0, 0));
+    reduce(32, 128, 3, ColMap{{128, 0}, {0, 0}, {0, 0}}, 11);
+    return nrf_launch_status();
+}

@@ -1,0 +1,281 @@
+// Device-side building blocks shared by the forward (mlp_fp32.hip) and backward (mlp_bwd.hip)
+// register-chained MFMA kernels: the LDS weight ring, the chained GEMM layer, the encoding.
+#pragma once
+#include "nrf_common.h"
+
+using namespace nrf;
+
+#define NRF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// The weight stream reaches the matrix cores through an LDS ring shared by the workgroup's 4
+// waves: 16-step (16 KiB) chunks, filled by global_load_lds_dwordx4 (LDS-DMA, no VGPRs) kRing-1
+// chunks ahead of use, one raw s_barrier per chunk and a COUNTED vmcnt so the prefetches stay in
+// flight across it.  The kernel is persistent (one workgroup per CU) and the stream wraps, so
+// the ring never drains between tiles.  Every layer is a whole number of chunks.
+#ifndef NRF_CHUNK_STEPS
+#define NRF_CHUNK_STEPS 16
+#endif
+#ifndef NRF_RING
+#define NRF_RING 5
+#endif
+constexpr int kChunkSteps = NRF_CHUNK_STEPS;
+constexpr int kChunkBytes = kChunkSteps * kStepFloats * 4;  // 16 KiB
+constexpr int kRing = NRF_RING;
+constexpr int kChunks = kStreamSteps / kChunkSteps;  // 145
+static_assert(kStreamSteps % kChunkSteps == 0, "layers must be chunk aligned");
+static_assert(kStepsL0 % kChunkSteps == 0 && kStepsHidden % kChunkSteps == 0 && kStepsSkip % kChunkSteps == 0 &&
+              kStepsViews % kChunkSteps == 0, "layers must be chunk aligned");
+constexpr int kLdsConstOff = kRing * kChunkBytes;              // biases + head weights live after the ring
+constexpr int kLdsBytes = kLdsConstOff + kSmallFloats * 4;     // 80 KiB + 12.1 KiB
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+
+struct WeightStream {
+    const char* gnext;  // per lane: address of this lane's 16 B of piece 4w of the next chunk to prefetch
+    const char* gbegin; // same for chunk 0
+    const char* gend;   // same for chunk kChunks (one past the end: wrap point)
+    unsigned lds_base;  // LDS byte address of smem + wave * 4 KiB (this wave fills pieces 4w..4w+3)
+    char* smem;
+    int pf_slot, rd_slot;
+    const float4* rd;   // this lane's float4 of step 0 of the chunk being read
+    float4 w;           // weights of the next step to be multiplied (already read from LDS)
+};
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0 + 1 KiB).
+// Inline asm on purpose: hipcc's waitcnt pass orders every ds_read behind ALL outstanding
+// LDS-DMA it knows of (s_waitcnt vmcnt(0)), which would serialise the ring; issued from asm the
+// loads are invisible to it and are ordered by ws_acquire's counted vmcnt + barrier instead.
+__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
+#ifdef NRF_GLDS_SAVE_M0
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+#else
+    // M0 is not saved/restored: nothing else in this kernel uses it (checked in the .s: the only
+    // m0 writes are these), and the restore would have to wait for the DMA to consume M0.
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+#endif
+}
+
+// piece j (0..3) of this wave's share of the chunk being prefetched
+__device__ __forceinline__ void ws_prefetch_piece(const WeightStream& st, int j) {
+#if defined(NRF_ABLATE_NOSYNC) || defined(NRF_ABLATE_NOGLDS)  // diagnostic builds only (tools/ubench/mlp_ablate.hip): results are wrong
+    return;
+#endif
+    glds16(st.gnext + j * 1024, st.lds_base + unsigned(st.pf_slot) * kChunkBytes + j * 1024);
+}
+
+__device__ __forceinline__ void ws_prefetch_advance(WeightStream& st) {
+    const char* nx = st.gnext + kChunkBytes;
+    st.gnext = nx == st.gend ? st.gbegin : nx;
+    // keep the address a run-time value: the schedule repeats every tile, and LICM would otherwise
+    // hoist all 145 chunk addresses out of the tile loop and spill them
+    asm volatile("" : "+v"(st.gnext));
+    st.pf_slot = st.pf_slot + 1 == kRing ? 0 : st.pf_slot + 1;
+}
+
+// Make the next chunk readable: my own 4 pieces of it have landed once at most 4*(kRing-2)
+// younger VMEM ops are outstanding; the barrier then covers the other waves' pieces and also
+// says every wave is done reading the previous chunk, whose slot the caller refills right away
+// (ws_prefetch_piece x4 + ws_prefetch_advance, spread between MFMAs).
+__device__ __forceinline__ void ws_acquire(WeightStream& st, int lane) {
+#if !defined(NRF_ABLATE_NOSYNC) && !defined(NRF_ABLATE_NOBARRIER)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(4 * (kRing - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+    st.rd_slot = st.rd_slot + 1 == kRing ? 0 : st.rd_slot + 1;
+    st.rd = reinterpret_cast<const float4*>(st.smem + st.rd_slot * kChunkBytes) + lane;
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float t;  // one v_max_f32 (fmaxf() costs a second, canonicalising v_max for signalling NaNs)
+        asm("v_max_f32 %0, 0, %1" : "=v"(t) : "v"(v[i]));
+        r[i] = t;
+    }
+    return r;
+}
+
+// One GEMM layer of the chain for this wave's 32 points: Y[ob] = init + sum_k W . [pre, X, post]
+// where X = op(Y of the previous layer).  Y holds raw (pre-activation) outputs; the transformed
+// copy X[i] = op(i, Y[i]) is made just in time while output block 0 is being accumulated (block i
+// of Y is not overwritten before output block i starts, X[0] is made before Y[0] is
+// re-initialised), so the VALU work runs under the matrix pipe and every layer has the same
+// X -> Y orientation: identical layers share one unrolled body inside a run-time loop and the
+// forward kernel (2112 unrolled MFMAs, ~48 KB of code) stays inside the 64 KB instruction cache.
+// `op` is a functor: relu / copy in the plain forward, relu + save + sign mask in the training
+// forward, mask + save in the backward (dgrad) chain.
+enum { INIT_BIAS = 0, INIT_ACCUM = 1, INIT_ZERO = 2 };
+
+struct OpCopy {
+    __device__ __forceinline__ f32x16 operator()(int, f32x16 y) { return y; }
+};
+struct OpRelu {
+    __device__ __forceinline__ f32x16 operator()(int, f32x16 y) {
+#ifdef NRF_ABLATE_NOACT
+        return y;
+#else
+        return relu16(y);
+#endif
+    }
+};
+
+template <int NOB, int NPRE, int NHID, int NPOST, int INIT, class InOp>
+__device__ __forceinline__ void mfma_layer(WeightStream& st, int lane, const float* bias_h, const f32x16* pre,
+                                           f32x16* X, const f32x16* post, f32x16* Y, InOp& op) {
+    constexpr int NKB = NPRE + NHID + NPOST;
+    constexpr int NS = NOB * NKB * 4;
+    static_assert(NS % kChunkSteps == 0, "layer must be a whole number of chunks");
+    // The weights of step s+1 are read from LDS before the MFMAs of step s are issued (the read
+    // latency hides under 256 matrix-core cycles).  The ring hand-over to the next chunk -- also
+    // the next layer's or next tile's first chunk -- happens ahead of a chunk's LAST step, and
+    // the 4 LDS-DMA issues that refill the freed slot go one into each MFMA gap of that step.
+    if (NHID > 0) X[0] = op(0, Y[0]);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        if (INIT == INIT_BIAS) Y[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+        if (INIT == INIT_ZERO) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Y[ob][t] = 0.f;
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (ob == 0 && kb > NPRE && kb < NPRE + NHID) X[kb - NPRE] = op(kb - NPRE, Y[kb - NPRE]);
+            const f32x16 x = kb < NPRE ? pre[kb] : (kb < NPRE + NHID ? X[kb - NPRE] : post[kb - NPRE - NHID]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = (ob * NKB + kb) * 4 + q;
+                const bool hand = (s + 1) % kChunkSteps == 0;
+                const float4 w = st.w;
+                if (hand) ws_acquire(st, lane);
+#ifndef NRF_ABLATE_NOLDS
+                st.w = st.rd[((s + 1) % kChunkSteps) * 64];
+#endif
+                Y[ob] = NRF_MFMA(w.x, x[4 * q + 0], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 0); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA(w.y, x[4 * q + 1], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 1); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA(w.z, x[4 * q + 2], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 2); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA(w.w, x[4 * q + 3], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 3); ws_prefetch_advance(st); __builtin_amdgcn_sched_barrier(0); }
+            }
+        }
+    }
+}
+
+// Start the ring: fill all kRing slots from the stream [gbegin, gend), then take chunk 0.
+__device__ __forceinline__ void ws_start(WeightStream& st, const char* stream_base, int n_chunks, char* smem,
+                                         int wave, int lane) {
+    st.gbegin = stream_base + wave * 4096 + lane * 16;
+    st.gend = st.gbegin + size_t(n_chunks) * kChunkBytes;
+    st.gnext = st.gbegin;
+    st.smem = smem;
+    st.lds_base = __builtin_amdgcn_readfirstlane(
+        unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * 4096u);
+    st.pf_slot = 0;
+#pragma unroll
+    for (int i = 0; i < kRing; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ws_prefetch_piece(st, jj);
+        ws_prefetch_advance(st);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRing - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = 0;
+    st.rd = reinterpret_cast<const float4*>(smem) + lane;
+    st.w = st.rd[0];
+}
+
+// ---- saved tensors of the training forward / backward (all [tile][row][32 points] fp32) ----
+// acts rows: encoding (64, kernel slot order), h0..h7 (relu'd, 256 each), feature (256), dir
+// encoding (32), hv (relu'd, 128).  dys rows: dY0..dY7, dY8 (= d feature), dYv (128), d raw (4).
+constexpr int kActPe = 0, kActH = 64, kActFeat = 64 + 8 * 256, kActDpe = kActFeat + 256, kActHv = kActDpe + 32;
+constexpr int kActRows = kActHv + 128;  // 2528
+constexpr int kDyFeat = 8 * 256, kDyV = 9 * 256, kDyRaw = kDyV + 128;  // + d(raw) as 4 rows [r, g, b, sigma]
+constexpr int kDyRows = kDyRaw + 32;    // 2464
+constexpr int kMaskLayers = 9;          // h0..h7, hv: 128 sign bits per lane = 4 words
+
+// store a 32-row block held as (reg t, lane-half h) -> row 32*blk + acc_row(t, h); `base` already
+// points at [tile][first row of the tensor][0] + (4*h*32 + point)
+__device__ __forceinline__ void store_block(float* base, int blk, f32x16 v) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) base[(32 * blk + (t & 3) + 8 * (t >> 2)) * 32] = v[t];
+}
+
+__device__ __forceinline__ unsigned sign_bits16(f32x16 v) {
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) m |= (v[t] > 0.f ? 1u : 0u) << t;
+    return m;
+}
+
+__device__ __forceinline__ f32x16 mask16(f32x16 v, unsigned bits) {
+    f32x16 r;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) r[t] = ((bits >> t) & 1u) ? v[t] : 0.f;
+    return r;
+}
+
+// sin(a) for lane-half 0, cos(a) for lane-half 1, branch-free.  Cody-Waite reduction with a
+// 3-term pi/2 (valid for |a| < 2^17, i.e. |x| < 256 at the 2^9 band; the scene lives in
+// |x| <= far = 6) and degree-7/8 minimax polynomials: max abs error 9.2e-8 over |a| <= 2e4
+// (tests/test_host_logic.py emulates it; torch's own sin is within 7e-8 of exact).
+__device__ __forceinline__ float sin_or_cos(float a, int h) {
+    const float k = rintf(a * 0.63661977236758134308f);
+    float r = fmaf(k, __uint_as_float(0xbfc90fdau), a);  // -1.570796251296997
+    r = fmaf(k, __uint_as_float(0xb3a22168u), r);        // -7.549789415861596e-08
+    r = fmaf(k, __uint_as_float(0xa7c234c4u), r);        // -5.390302529957765e-15
+    const float z = r * r;
+    float sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    sp = fmaf(sp * z, r, r);
+    float cp = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    cp = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
+    const int q = int(k) + h;  // cos(a) = sin(a + pi/2)
+    const float v = (q & 1) ? cp : sp;
+    return (q & 2) ? -v : v;
+}
+
+// 16 encoding slots of one k-block: trig part for slots n < 3L, then the raw inputs.
+template <int L, int KB>
+__device__ __forceinline__ f32x16 encode_block(float x, float y, float z, int h) {
+    f32x16 r;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int n = KB * 16 + t;
+        float v;
+        if (n < 3 * L) {
+            const float c = (n % 3) == 0 ? x : ((n % 3) == 1 ? y : z);
+#ifdef NRF_ABLATE_NOPE
+            v = c * float(1 << (n / 3)) + h;
+#else
+            v = sin_or_cos(c * float(1 << (n / 3)), h);
+#endif
+        } else if (n == 3 * L) {
+            v = h ? y : x;
+        } else if (n == 3 * L + 1) {
+            v = h ? 0.f : z;
+        } else {
+            v = 0.f;
+        }
+        r[t] = v;
+    }
+    return r;
+}
+

@@ -19,19 +19,7 @@
 //     the same bytes).  One float4 per lane feeds 4 MFMAs (256 matrix-core cycles).
 //   * PE (63 ch) and dir PE (27 ch) are computed in registers in the k-order the packed
 //     weights expect; alpha (256->1) and rgb (128->3) heads are VALU dot products.
-#include "nrf_common.h"
-
-using namespace nrf;
-
-// Kernel PE slot n of lane-half h -> column of the reference encoding
-// cat([x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]) (3 wide each), or -1.
-// Half 0 holds the sin terms, half 1 the cos terms; slots 3L, 3L+1 hold the raw input.
-__host__ __device__ static inline int pe_col(int n, int h, int L) {
-    if (n < 3 * L) return 3 + 6 * (n / 3) + 3 * h + (n % 3);
-    if (n == 3 * L) return h;               // x | y
-    if (n == 3 * L + 1) return h ? -1 : 2;  // z | pad
-    return -1;
-}
+#include "mlp_chain.h"
 
 // ------------------------------------------------------------------------------------
 // weight packing
@@ -43,6 +31,7 @@ struct PackLayer {
     int pre_kb, hid_kb, post_kb;  // K blocks of 32: PE before / hidden / PE after
     int pre_L, post_L;            // PE frequencies of the pre / post part
     int pre_col0, hid_col0, post_col0;  // first source column of each part
+    int transpose;                      // hidden part only: stream W^T (rows = input features) for the dgrad chain
 };
 
 __global__ void pack_layer_kernel(PackLayer p) {
@@ -59,7 +48,10 @@ __global__ void pack_layer_kernel(PackLayer p) {
         const int c = pe_col(kbpos * 16 + t, h, p.pre_L);
         if (c >= 0) v = p.W[row + p.pre_col0 + c];
     } else if (kbpos < p.pre_kb + p.hid_kb) {
-        v = p.W[row + p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
+        if (p.transpose)  // A[i = input feature][k = output feature] = W[k][i]
+            v = p.W[int64_t(32 * (kbpos - p.pre_kb) + acc_row(t, h)) * p.ldw + p.hid_col0 + ob * 32 + (lane & 31)];
+        else
+            v = p.W[row + p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
     } else {
         const int c = pe_col((kbpos - p.pre_kb - p.hid_kb) * 16 + t, h, p.post_L);
         if (c >= 0) v = p.W[row + p.post_col0 + c];
@@ -141,226 +133,68 @@ NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, fl
     return nrf_launch_status();
 }
 
+NRF_EXPORT int64_t nrf_packed_bwd_floats(void) { return kBwdPackedFloats; }
+
+// Stream for the backward (dgrad) chain, in the order it is consumed: views^T (hidden columns
+// only: the direction encoding needs no gradient), feature^T, pts7^T ... pts1^T (pts5: hidden
+// columns 63..318 only).  d(input of layer l) = W_l^T . d(output of layer l).
+NRF_EXPORT int nrf_pack_weights_transposed(const float* const* w, float* packed_t, nrf_stream_t stream_) {
+    if (!w || !packed_t) return NRF_ERR_NULL;
+    for (int i = 0; i < NRF_NUM_LAYERS; ++i)
+        if (!w[i]) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed_t)) return NRF_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    nrf_launch_begin();
+    int step = 0;
+    auto launch = [&](const float* W, int ldw, int in_blocks, int out_blocks, int col0) {
+        PackLayer p{W, packed_t + int64_t(step) * kStepFloats, ldw, in_blocks, 0, out_blocks, 0, 0, 0, 0, col0, 0, 1};
+        const int total = in_blocks * out_blocks * 4 * kStepFloats;
+        pack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+        step += in_blocks * out_blocks * 4;
+    };
+    launch(w[10], 283, 8, 4, 0);  // views^T: 256 inputs x 128 outputs
+    launch(w[8], 256, 8, 8, 0);   // feature^T
+    for (int l = 7; l >= 1; --l) launch(w[l], l == 5 ? 319 : 256, 8, 8, l == 5 ? 63 : 0);
+    (void)hipMemsetAsync(packed_t + int64_t(kBwdSteps) * kStepFloats, 0, size_t(kPrefetch) * kStepFloats * 4, stream);
+    return nrf_launch_status();
+}
+
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
-#define NRF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
 namespace {
 
-// The weight stream reaches the matrix cores through an LDS ring shared by the workgroup's 4
-// waves: 16-step (16 KiB) chunks, filled by global_load_lds_dwordx4 (LDS-DMA, no VGPRs) kRing-1
-// chunks ahead of use, one raw s_barrier per chunk and a COUNTED vmcnt so the prefetches stay in
-// flight across it.  The kernel is persistent (one workgroup per CU) and the stream wraps, so
-// the ring never drains between tiles.  Every layer is a whole number of chunks.
-#ifndef NRF_CHUNK_STEPS
-#define NRF_CHUNK_STEPS 16
-#endif
-#ifndef NRF_RING
-#define NRF_RING 5
-#endif
-constexpr int kChunkSteps = NRF_CHUNK_STEPS;
-constexpr int kChunkBytes = kChunkSteps * kStepFloats * 4;  // 16 KiB
-constexpr int kRing = NRF_RING;
-constexpr int kChunks = kStreamSteps / kChunkSteps;  // 145
-static_assert(kStreamSteps % kChunkSteps == 0, "layers must be chunk aligned");
-static_assert(kStepsL0 % kChunkSteps == 0 && kStepsHidden % kChunkSteps == 0 && kStepsSkip % kChunkSteps == 0 &&
-              kStepsViews % kChunkSteps == 0, "layers must be chunk aligned");
-constexpr int kLdsConstOff = kRing * kChunkBytes;              // biases + head weights live after the ring
-constexpr int kLdsBytes = kLdsConstOff + kSmallFloats * 4;     // 80 KiB + 12.1 KiB
-
-typedef __attribute__((address_space(3))) void* lds_vptr;
-typedef const __attribute__((address_space(1))) void* glb_vptr;
-
-struct WeightStream {
-    const char* gnext;  // per lane: address of this lane's 16 B of piece 4w of the next chunk to prefetch
-    const char* gbegin; // same for chunk 0
-    const char* gend;   // same for chunk kChunks (one past the end: wrap point)
-    unsigned lds_base;  // LDS byte address of smem + wave * 4 KiB (this wave fills pieces 4w..4w+3)
-    char* smem;
-    int pf_slot, rd_slot;
-    const float4* rd;   // this lane's float4 of step 0 of the chunk being read
-    float4 w;           // weights of the next step to be multiplied (already read from LDS)
+// relu / copy + store the activated block + collect its sign bits (training forward)
+template <bool RELU>
+struct OpFwdSave {
+    float* dst;      // acts + (tile * kActRows + first row) * 32 + 4 * h * 32 + point
+    unsigned* mdst;  // masks + ((tile * kMaskLayers + layer) * 4) * 64 + lane, or nullptr
+    unsigned cur;
+    __device__ __forceinline__ f32x16 operator()(int i, f32x16 y) {
+        const f32x16 x = RELU ? relu16(y) : y;
+        store_block(dst, i, x);
+        if (RELU) {
+            const unsigned bits = sign_bits16(x);
+            if (i & 1) mdst[(i >> 1) * 64] = cur | (bits << 16);
+            else cur = bits;
+        }
+        return x;
+    }
 };
-
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0 + 1 KiB).
-// Inline asm on purpose: hipcc's waitcnt pass orders every ds_read behind ALL outstanding
-// LDS-DMA it knows of (s_waitcnt vmcnt(0)), which would serialise the ring; issued from asm the
-// loads are invisible to it and are ordered by ws_acquire's counted vmcnt + barrier instead.
-__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
-#ifdef NRF_GLDS_SAVE_M0
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-#else
-    // M0 is not saved/restored: nothing else in this kernel uses it (checked in the .s: the only
-    // m0 writes are these), and the restore would have to wait for the DMA to consume M0.
-    asm volatile(
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, off"
-        :
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-#endif
-}
-
-// piece j (0..3) of this wave's share of the chunk being prefetched
-__device__ __forceinline__ void ws_prefetch_piece(const WeightStream& st, int j) {
-#if defined(NRF_ABLATE_NOSYNC) || defined(NRF_ABLATE_NOGLDS)  // diagnostic builds only (tools/ubench/mlp_ablate.hip): results are wrong
-    return;
-#endif
-    glds16(st.gnext + j * 1024, st.lds_base + unsigned(st.pf_slot) * kChunkBytes + j * 1024);
-}
-
-__device__ __forceinline__ void ws_prefetch_advance(WeightStream& st) {
-    const char* nx = st.gnext + kChunkBytes;
-    st.gnext = nx == st.gend ? st.gbegin : nx;
-    // keep the address a run-time value: the schedule repeats every tile, and LICM would otherwise
-    // hoist all 145 chunk addresses out of the tile loop and spill them
-    asm volatile("" : "+v"(st.gnext));
-    st.pf_slot = st.pf_slot + 1 == kRing ? 0 : st.pf_slot + 1;
-}
-
-// Make the next chunk readable: my own 4 pieces of it have landed once at most 4*(kRing-2)
-// younger VMEM ops are outstanding; the barrier then covers the other waves' pieces and also
-// says every wave is done reading the previous chunk, whose slot the caller refills right away
-// (ws_prefetch_piece x4 + ws_prefetch_advance, spread between MFMAs).
-__device__ __forceinline__ void ws_acquire(WeightStream& st, int lane) {
-#if !defined(NRF_ABLATE_NOSYNC) && !defined(NRF_ABLATE_NOBARRIER)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(4 * (kRing - 2)) : "memory");
-    __builtin_amdgcn_s_barrier();
-#endif
-    st.rd_slot = st.rd_slot + 1 == kRing ? 0 : st.rd_slot + 1;
-    st.rd = reinterpret_cast<const float4*>(st.smem + st.rd_slot * kChunkBytes) + lane;
-}
-
-__device__ __forceinline__ f32x16 relu16(f32x16 v) {
-    f32x16 r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float t;  // one v_max_f32 (fmaxf() costs a second, canonicalising v_max for signalling NaNs)
-        asm("v_max_f32 %0, 0, %1" : "=v"(t) : "v"(v[i]));
-        r[i] = t;
-    }
-    return r;
-}
-
-// One GEMM layer of the chain for this wave's 32 points: Y[ob] = bias + sum_k W . [pre, X, post]
-// where X = act(Y of the previous layer).  Y holds raw (pre-activation) outputs; the activated
-// copy X[i] = act(Y[i]) is made just in time while output block 0 is being accumulated (block i
-// of Y is not overwritten before output block i starts, X[0] is made before Y[0] is
-// re-initialised), so the VALU work runs under the matrix pipe and every layer has the same
-// X -> Y orientation: identical layers share one unrolled body inside a run-time loop and the
-// whole kernel (3136 unrolled MFMAs, ~45 KB of code) stays inside the 64 KB instruction cache.
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_COPY = 2 };
-template <int NOB, int NPRE, int NHID, int NPOST, int ACT, bool ACCUM = false>
-__device__ __forceinline__ void mfma_layer(WeightStream& st, int lane, const float* bias_h, const f32x16* pre,
-                                           f32x16* X, const f32x16* post, f32x16* Y) {
-    constexpr int NKB = NPRE + NHID + NPOST;
-    constexpr int NS = NOB * NKB * 4;
-    static_assert(NS % kChunkSteps == 0, "layer must be a whole number of chunks");
-    // The weights of step s+1 are read from LDS before the MFMAs of step s are issued (the read
-    // latency hides under 256 matrix-core cycles).  The ring hand-over to the next chunk -- also
-    // the next layer's or next tile's first chunk -- happens ahead of a chunk's LAST step, and
-    // the 4 LDS-DMA issues that refill the freed slot go one into each MFMA gap of that step.
-#ifdef NRF_ABLATE_NOACT
-#define NRF_ACT(v) (v)
-#else
-#define NRF_ACT(v) (ACT == ACT_RELU ? relu16(v) : (v))
-#endif
-    if (NHID > 0) X[0] = NRF_ACT(Y[0]);
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        if (!ACCUM) Y[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            if (ob == 0 && kb > NPRE && kb < NPRE + NHID) X[kb - NPRE] = NRF_ACT(Y[kb - NPRE]);
-            const f32x16 x = kb < NPRE ? pre[kb] : (kb < NPRE + NHID ? X[kb - NPRE] : post[kb - NPRE - NHID]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int s = (ob * NKB + kb) * 4 + q;
-                const bool hand = (s + 1) % kChunkSteps == 0;
-                const float4 w = st.w;
-                if (hand) ws_acquire(st, lane);
-#ifndef NRF_ABLATE_NOLDS
-                st.w = st.rd[((s + 1) % kChunkSteps) * 64];
-#endif
-                Y[ob] = NRF_MFMA(w.x, x[4 * q + 0], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 0); __builtin_amdgcn_sched_barrier(0); }
-                Y[ob] = NRF_MFMA(w.y, x[4 * q + 1], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 1); __builtin_amdgcn_sched_barrier(0); }
-                Y[ob] = NRF_MFMA(w.z, x[4 * q + 2], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 2); __builtin_amdgcn_sched_barrier(0); }
-                Y[ob] = NRF_MFMA(w.w, x[4 * q + 3], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); ws_prefetch_piece(st, 3); ws_prefetch_advance(st); __builtin_amdgcn_sched_barrier(0); }
-            }
-        }
-    }
-}
-
-// sin(a) for lane-half 0, cos(a) for lane-half 1, branch-free.  Cody-Waite reduction with a
-// 3-term pi/2 (valid for |a| < 2^17, i.e. |x| < 256 at the 2^9 band; the scene lives in
-// |x| <= far = 6) and degree-7/8 minimax polynomials: max abs error 9.2e-8 over |a| <= 2e4
-// (tests/test_host_logic.py emulates it; torch's own sin is within 7e-8 of exact).
-__device__ __forceinline__ float sin_or_cos(float a, int h) {
-    const float k = rintf(a * 0.63661977236758134308f);
-    float r = fmaf(k, __uint_as_float(0xbfc90fdau), a);  // -1.570796251296997
-    r = fmaf(k, __uint_as_float(0xb3a22168u), r);        // -7.549789415861596e-08
-    r = fmaf(k, __uint_as_float(0xa7c234c4u), r);        // -5.390302529957765e-15
-    const float z = r * r;
-    float sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
-    sp = fmaf(sp * z, r, r);
-    float cp = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-    cp = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
-    const int q = int(k) + h;  // cos(a) = sin(a + pi/2)
-    const float v = (q & 1) ? cp : sp;
-    return (q & 2) ? -v : v;
-}
-
-// 16 encoding slots of one k-block: trig part for slots n < 3L, then the raw inputs.
-template <int L, int KB>
-__device__ __forceinline__ f32x16 encode_block(float x, float y, float z, int h) {
-    f32x16 r;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int n = KB * 16 + t;
-        float v;
-        if (n < 3 * L) {
-            const float c = (n % 3) == 0 ? x : ((n % 3) == 1 ? y : z);
-#ifdef NRF_ABLATE_NOPE
-            v = c * float(1 << (n / 3)) + h;
-#else
-            v = sin_or_cos(c * float(1 << (n / 3)), h);
-#endif
-        } else if (n == 3 * L) {
-            v = h ? y : x;
-        } else if (n == 3 * L + 1) {
-            v = h ? 0.f : z;
-        } else {
-            v = 0.f;
-        }
-        r[t] = v;
-    }
-    return r;
-}
 
 // Persistent: gridDim.x <= number of CUs, one 4-wave workgroup per CU, one wave per SIMD.
 // Tile group tg = 4 consecutive 32-point tiles, one per wave; all waves run every group (the
 // barriers of the weight ring are workgroup-wide), waves past the end just do not store.
+// SAVE (training): also writes every layer's activated input (`acts`) and relu sign bits (`masks`)
+// for the backward kernels; both buffers must cover n_groups * 4 tiles.
+template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict__ packed,
                                                          const float* __restrict__ a0,  // rays_o | pts
                                                          const float* __restrict__ a1,  // rays_d | dirs
                                                          const float* __restrict__ zbuf, int64_t z_stride,
                                                          int tiles_per_ray, int rays_mode, int64_t n_points,
-                                                         int64_t n_groups, float4* __restrict__ raw) {
+                                                         int64_t n_groups, float4* __restrict__ raw,
+                                                         float* __restrict__ acts, unsigned* __restrict__ masks) {
     __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -377,25 +211,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict
     const float* bias_h = cst + h * 16;                                      // [layer][ob][h][16]
 
     WeightStream st;
-    st.gbegin = reinterpret_cast<const char*>(packed) + wave * 4096 + lane * 16;
-    st.gend = st.gbegin + size_t(kChunks) * kChunkBytes;
-    st.gnext = st.gbegin;
-    st.smem = smem;
-    st.lds_base = __builtin_amdgcn_readfirstlane(
-        unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * 4096u);
-    st.pf_slot = 0;
-    st.rd_slot = kRing - 1;
-#pragma unroll
-    for (int i = 0; i < kRing; ++i) {  // fill the whole ring, then take chunk 0
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) ws_prefetch_piece(st, jj);
-        ws_prefetch_advance(st);
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRing - 1)) : "memory");
-    __builtin_amdgcn_s_barrier();
-    st.rd_slot = 0;
-    st.rd = reinterpret_cast<const float4*>(smem) + lane;
-    st.w = st.rd[0];
+    ws_start(st, reinterpret_cast<const char*>(packed), kChunks, smem, wave, lane);
 
     for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
         const int64_t tile = tg * 4 + wave;
@@ -426,13 +242,29 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict
         pe[0] = encode_block<10, 0>(px, py, pz, h);
         pe[1] = encode_block<10, 1>(px, py, pz, h);
         dpe[0] = encode_block<4, 0>(dx, dy, dz, h);
+        float* arow = nullptr;     // this lane's column of the tile's saved rows
+        unsigned* mrow = nullptr;
+        if (SAVE) {
+            arow = acts + tile * (int64_t(kActRows) * 32) + 4 * h * 32 + j;
+            mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+            store_block(arow + kActPe * 32, 0, pe[0]);
+            store_block(arow + kActPe * 32, 1, pe[1]);
+            store_block(arow + kActDpe * 32, 0, dpe[0]);
+        }
 
         f32x16 X[8], Y[8];
-        mfma_layer<8, 2, 0, 0, ACT_NONE>(st, lane, bias_h, pe, X, nullptr, Y);               // pts_linears.0
-        for (int li = 1; li <= 8; ++li) {                                                     // pts 1..7, feature
-            mfma_layer<8, 0, 8, 0, ACT_RELU>(st, lane, bias_h + li * 256, nullptr, X, nullptr, Y);
+        OpCopy op_none;
+        OpRelu op_relu;
+        mfma_layer<8, 2, 0, 0, INIT_BIAS>(st, lane, bias_h, pe, X, nullptr, Y, op_none);      // pts_linears.0
+        for (int li = 1; li <= 8; ++li) {                                                      // pts 1..7, feature
+            if (SAVE) {  // X = h_{li-1} = relu(Y): saved as the input of layer li, its signs as mask li-1
+                OpFwdSave<true> op{arow + (kActH + (li - 1) * 256) * 32, mrow + (li - 1) * 4 * 64, 0u};
+                mfma_layer<8, 0, 8, 0, INIT_BIAS>(st, lane, bias_h + li * 256, nullptr, X, nullptr, Y, op);
+            } else {
+                mfma_layer<8, 0, 8, 0, INIT_BIAS>(st, lane, bias_h + li * 256, nullptr, X, nullptr, Y, op_relu);
+            }
             if (li == 5)  // skip: cat([pe, h]) (network.py:58) = the hidden part above + this PE pass on top
-                mfma_layer<8, 2, 0, 0, ACT_NONE, true>(st, lane, nullptr, pe, X, nullptr, Y);
+                mfma_layer<8, 2, 0, 0, INIT_ACCUM>(st, lane, nullptr, pe, X, nullptr, Y, op_none);
         }
         // X = relu(h7) (made while feature_linear ran): alpha_linear as a VALU dot over this half's 128 features
         float sigma = 0.f;
@@ -446,13 +278,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict
             }
         }
         // views_linears.0 on cat([feature (no activation), dir PE]) -> 128
-        mfma_layer<4, 0, 8, 1, ACT_COPY>(st, lane, bias_h + 9 * 256, nullptr, X, dpe, Y);
+        if (SAVE) {
+            OpFwdSave<false> op{arow + kActFeat * 32, nullptr, 0u};
+            mfma_layer<4, 0, 8, 1, INIT_BIAS>(st, lane, bias_h + 9 * 256, nullptr, X, dpe, Y, op);
+        } else {
+            mfma_layer<4, 0, 8, 1, INIT_BIAS>(st, lane, bias_h + 9 * 256, nullptr, X, dpe, Y, op_none);
+        }
         float r = 0.f, g = 0.f, b = 0.f;
         {
             const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
+            OpFwdSave<true> ops{SAVE ? arow + kActHv * 32 : nullptr, SAVE ? mrow + 8 * 4 * 64 : nullptr, 0u};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                const f32x16 hv = relu16(Y[kb]);
+                const f32x16 hv = SAVE ? ops(kb, Y[kb]) : relu16(Y[kb]);
                 const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
                 const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
                 const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
@@ -478,7 +316,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const float* __restrict
 }
 
 int launch_mlp(const float* packed, const float* a0, const float* a1, const float* z, int64_t z_stride,
-               int tiles_per_ray, int rays_mode, int64_t n_points, float* raw, hipStream_t stream) {
+               int tiles_per_ray, int rays_mode, int64_t n_points, float* raw, hipStream_t stream,
+               float* acts = nullptr, unsigned* masks = nullptr) {
     const int64_t tiles = (n_points + 31) / 32;
     const int64_t groups = (tiles + 3) / 4;
     int dev = 0, cus = 256;
@@ -486,8 +325,13 @@ int launch_mlp(const float* packed, const float* a0, const float* a1, const floa
     if (cus <= 0) cus = 256;
     const unsigned grid = unsigned(groups < cus ? groups : cus);
     nrf_launch_begin();
-    mlp_fwd_kernel<<<dim3(grid), 256, 0, stream>>>(packed, a0, a1, z, z_stride, tiles_per_ray, rays_mode, n_points,
-                                                   groups, reinterpret_cast<float4*>(raw));
+    if (acts)
+        mlp_fwd_kernel<true><<<dim3(grid), 256, 0, stream>>>(packed, a0, a1, z, z_stride, tiles_per_ray, rays_mode,
+                                                             n_points, groups, reinterpret_cast<float4*>(raw), acts, masks);
+    else
+        mlp_fwd_kernel<false><<<dim3(grid), 256, 0, stream>>>(packed, a0, a1, z, z_stride, tiles_per_ray, rays_mode,
+                                                              n_points, groups, reinterpret_cast<float4*>(raw), nullptr,
+                                                              nullptr);
     return nrf_launch_status();
 }
 
@@ -518,4 +362,32 @@ NRF_EXPORT int nrf_mlp_forward_points(const float* packed, const float* pts, con
     if (n_points == 0) return NRF_OK;
     if (int st = check_common(packed, pts, dirs, raw)) return st;
     return launch_mlp(packed, pts, dirs, nullptr, 0, 1, 0, n_points, raw, static_cast<hipStream_t>(stream));
+}
+
+// Training forward: nrf_mlp_forward_rays + the saved tensors the backward needs.
+NRF_EXPORT int64_t nrf_mlp_train_tiles(int64_t n_rays, int n_samples) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0) return NRF_ERR_SHAPE;
+    const int64_t tiles = n_rays * (n_samples / 32);
+    return (tiles + 3) / 4 * 4;  // buffers cover whole 4-tile groups
+}
+NRF_EXPORT int64_t nrf_mlp_acts_bytes(int64_t n_rays, int n_samples) {
+    const int64_t t = nrf_mlp_train_tiles(n_rays, n_samples);
+    return t < 0 ? t : t * int64_t(kActRows) * 32 * 4;
+}
+NRF_EXPORT int64_t nrf_mlp_masks_bytes(int64_t n_rays, int n_samples) {
+    const int64_t t = nrf_mlp_train_tiles(n_rays, n_samples);
+    return t < 0 ? t : t * int64_t(kMaskLayers) * 4 * 64 * 4;
+}
+
+NRF_EXPORT int nrf_mlp_forward_rays_train(const float* packed, const float* rays_o, const float* rays_d, const float* z,
+                                          int64_t z_stride, int64_t n_rays, int n_samples, float* raw, float* acts,
+                                          uint32_t* masks, nrf_stream_t stream) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (int st = check_common(packed, rays_o, rays_d, raw)) return st;
+    if (!z || !acts || !masks) return NRF_ERR_NULL;
+    if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
+    return launch_mlp(packed, rays_o, rays_d, z, z_stride, n_samples / 32, 1, n_rays * n_samples, raw,
+                      static_cast<hipStream_t>(stream), acts, masks);
 }

@@ -61,7 +61,22 @@ constexpr int64_t kOffRgbB = kOffRgbW + 3 * 128;                               /
 constexpr int64_t kPackedFloats = kOffRgbB + 16;
 constexpr int kSmallFloats = int(kPackedFloats - kOffBias);
 
+// backward (dgrad) stream: views^T 8x4x4 steps, then feature^T and pts7^T..pts1^T at 8x8x4 each
+constexpr int kBwdSteps = 8 * 4 * 4 + 8 * kStepsHidden;  // 2176
+constexpr int64_t kBwdPackedFloats = int64_t(kBwdSteps + kPrefetch) * kStepFloats;
+
 // row of a 32x32 MFMA accumulator held in register t of lane-half h
 __host__ __device__ constexpr int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
+
+// Kernel PE slot n of lane-half h -> column of the reference encoding
+// cat([x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]) (3 wide each), or -1.
+// Half 0 holds the sin terms, half 1 the cos terms; slots 3L, 3L+1 hold the raw input.
+__host__ __device__ inline int pe_col(int n, int h, int L) {
+    if (n < 3 * L) return 3 + 6 * (n / 3) + 3 * h + (n % 3);
+    if (n == 3 * L) return h;               // x | y
+    if (n == 3 * L + 1) return h ? -1 : 2;  // z | pad
+    return -1;
+}
+
 
 }  // namespace nrf

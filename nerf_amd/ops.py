@@ -144,3 +144,75 @@ def sample_fine(weights, bins, z_coarse, u, u2, u_fine=None, want_debug: bool = 
                                     0 if z_coarse.ndim == 1 else nc, _ptr(u), _ptr(u2), _ptr(u_fine), R, nc, ni,
                                     _ptr(z_out), _ptr(fine), _ptr(idx), _stream(weights)), "nrf_sample_fine")
     return (z_out, fine, idx) if want_debug else z_out
+
+
+# ---- training step ------------------------------------------------------------------------
+def model_param_floats() -> int:
+    return int(lib().nrf_model_param_floats())
+
+
+def pack_weights_transposed(weights, out: torch.Tensor | None = None) -> torch.Tensor:
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    dev = ws[0].device
+    if out is None:
+        out = torch.empty(int(lib().nrf_packed_bwd_floats()), dtype=torch.float32, device=dev)
+    wp = (C.c_void_p * 12)(*[w.data_ptr() for w in ws])
+    with torch.cuda.device(dev):
+        check(lib().nrf_pack_weights_transposed(wp, _ptr(out), _stream(out)), "nrf_pack_weights_transposed")
+    return out
+
+
+def mlp_forward_rays_train(packed, rays_o, rays_d, z):
+    """-> (raw (R,S,4), acts, masks): the saved tensors are opaque buffers for mlp_backward."""
+    rays_o, rays_d, z = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z, "z")
+    R, S = rays_o.shape[0], z.shape[-1]
+    stride = 0 if z.ndim == 1 else S
+    dev = rays_o.device
+    L = lib()
+    raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
+    acts = torch.empty(max(int(L.nrf_mlp_acts_bytes(R, S)), 4) // 4, dtype=torch.float32, device=dev)
+    masks = torch.empty(max(int(L.nrf_mlp_masks_bytes(R, S)), 4) // 4, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(L.nrf_mlp_forward_rays_train(_ptr(packed), _ptr(rays_o), _ptr(rays_d), _ptr(z), stride, R, S, _ptr(raw),
+                                           _ptr(acts), _ptr(masks), _stream(raw)), "nrf_mlp_forward_rays_train")
+    return raw, acts, masks
+
+
+def composite_backward(raw, z, white_bkgd, g_rgb=None, g_depth=None, g_acc=None) -> torch.Tensor:
+    raw, z = _f32(raw, "raw"), _f32(z, "z")
+    R, S = raw.shape[0], raw.shape[1]
+    stride = 0 if z.ndim == 1 else S
+    gs = [None if g is None else _f32(g, "grad").reshape(R, -1) for g in (g_rgb, g_depth, g_acc)]
+    g_raw = torch.empty_like(raw)
+    with torch.cuda.device(raw.device):
+        check(lib().nrf_composite_backward(_ptr(raw), _ptr(z), stride, R, S, int(bool(white_bkgd)), _ptr(gs[0]), _ptr(gs[1]),
+                                           _ptr(gs[2]), _ptr(g_raw), _stream(raw)), "nrf_composite_backward")
+    return g_raw
+
+
+def mlp_backward(packed, packed_t, g_raw, acts, masks, workspace: torch.Tensor | None = None) -> torch.Tensor:
+    """-> flat gradient (595,844,) of one model in state-dict order (weight then bias per layer)."""
+    g_raw = _f32(g_raw, "g_raw")
+    R, S = g_raw.shape[0], g_raw.shape[1]
+    dev = g_raw.device
+    L = lib()
+    need = int(L.nrf_mlp_backward_workspace_bytes(R, S))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    flat = torch.zeros(model_param_floats(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(L.nrf_mlp_backward(_ptr(packed), _ptr(packed_t), _ptr(g_raw), _ptr(acts), _ptr(masks), R, S, _ptr(workspace),
+                                 workspace.numel(), _ptr(flat), _stream(flat)), "nrf_mlp_backward")
+    return flat
+
+
+def split_flat_grad(flat: torch.Tensor):
+    """flat (595,844,) -> 12 (weight, bias) pairs shaped like LAYER_SHAPES (views, no copies)."""
+    out, o = [], 0
+    for (fo, fi) in LAYER_SHAPES:
+        w = flat[o:o + fo * fi].view(fo, fi)
+        o += fo * fi
+        b = flat[o:o + fo]
+        o += fo
+        out.append((w, b))
+    return out

@@ -33,6 +33,47 @@ def near_far_table(near: float, far: float, n: int) -> np.ndarray:
     return (f(near) * (f(1.0) - s) + f(far) * s).astype(f)
 
 
+class _RenderTrainFn(torch.autograd.Function):
+    """Coarse + fine render whose backward runs the HIP backward kernels.
+
+    Inputs after the renderer / ray arguments are the 48 parameters (coarse then fine model, each
+    in ops.LAYER_NAMES order, weight then bias) so autograd routes the flat gradients back to them.
+    """
+
+    @staticmethod
+    def forward(ctx, renderer, rays_o, rays_d, u, u2, u_coarse, u_fine, *params):
+        dev = rays_o.device
+        bins = renderer._bins
+        white = renderer.white_bkgd > 0
+        pc, pc_t = renderer._packed_model("model", dev), renderer._packed_model_t("model", dev)
+        pf, pf_t = renderer._packed_model("model_fine", dev), renderer._packed_model_t("model_fine", dev)
+        zc = bins if u_coarse is None else ops.perturb_samples(bins, u_coarse)
+        raw_c, acts_c, masks_c = ops.mlp_forward_rays_train(pc, rays_o, rays_d, zc)
+        c_rgb, c_depth, w_c, _ = ops.composite(raw_c, zc, white, True)
+        z_f = ops.sample_fine(w_c, bins, zc, u, u2, u_fine)      # integer bins + constants: no gradient
+        raw_f, acts_f, masks_f = ops.mlp_forward_rays_train(pf, rays_o, rays_d, z_f)
+        f_rgb, f_depth, _, f_acc = ops.composite(raw_f, z_f, white, False)
+        ctx.renderer, ctx.white = renderer, white
+        ctx.saved = (pc, pc_t, raw_c, zc, acts_c, masks_c, pf, pf_t, raw_f, z_f, acts_f, masks_f)
+        renderer.coarse_samples, renderer.fine_samples = zc, z_f
+        return c_rgb, c_depth, f_rgb, f_depth, f_acc
+
+    @staticmethod
+    def backward(ctx, g_c_rgb, g_c_depth, g_f_rgb, g_f_depth, g_f_acc):
+        pc, pc_t, raw_c, zc, acts_c, masks_c, pf, pf_t, raw_f, z_f, acts_f, masks_f = ctx.saved
+        r = ctx.renderer
+        g_raw_c = ops.composite_backward(raw_c, zc, ctx.white, g_c_rgb, g_c_depth, None)
+        flat_c = ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, r._bwd_workspace(raw_c))
+        g_raw_f = ops.composite_backward(raw_f, z_f, ctx.white, g_f_rgb, g_f_depth, g_f_acc)
+        flat_f = ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, r._bwd_workspace(raw_f))
+        ctx.saved = None
+        grads = []
+        for flat in (flat_c, flat_f):
+            for w, b in ops.split_flat_grad(flat):
+                grads += [w, b]
+        return (None,) * 7 + tuple(grads)
+
+
 class Renderer(nn.Module):
     def __init__(self, net, cfg=None):
         super().__init__()
@@ -62,6 +103,8 @@ class Renderer(nn.Module):
         self.fine_samples = None
         self.max_rays_per_call = 1 << 20
         self._packed = {}      # model name -> (version key, packed tensor)
+        self._packed_t = {}    # model name -> (version key, transposed stream for the backward)
+        self._bwd_ws = None
         self._bins = None
         self._workspace = None
 
@@ -85,6 +128,45 @@ class Renderer(nn.Module):
         self._packed[name] = (key, buf)
         return buf
 
+    def _model_params(self, name: str):
+        model = getattr(self.net, name)
+        params = []
+        for ln in ops.LAYER_NAMES:
+            mod = model
+            for part in ln.split("."):
+                mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+            params += [mod.weight, mod.bias]
+        return params
+
+    def _packed_model_t(self, name: str, device) -> torch.Tensor:
+        params = self._model_params(name)
+        key = tuple((p.data_ptr(), p._version) for p in params[0::2]) + (str(device),)
+        hit = self._packed_t.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        buf = ops.pack_weights_transposed(params[0::2], out=hit[1] if hit is not None else None)
+        self._packed_t[name] = (key, buf)
+        return buf
+
+    def _bwd_workspace(self, raw: torch.Tensor) -> torch.Tensor:
+        need = int(lib().nrf_mlp_backward_workspace_bytes(raw.shape[0], raw.shape[1]))
+        if self._bwd_ws is None or self._bwd_ws.device != raw.device or self._bwd_ws.numel() < need:
+            self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=raw.device)
+        return self._bwd_ws
+
+    def render_rays_train(self, rays_o, rays_d, u, u2, u_coarse=None, u_fine=None):
+        """Differentiable render (w.r.t. the network parameters): the training-step path."""
+        dev = rays_o.device
+        if self._bins is None or self._bins.device != dev:
+            self._bins = torch.from_numpy(near_far_table(self.near, self.far, self.N_samples)).to(dev)
+        params = self._model_params("model") + self._model_params("model_fine")
+        c_rgb, c_depth, f_rgb, f_depth, f_acc = _RenderTrainFn.apply(self, rays_o, rays_d, u, u2, u_coarse, u_fine, *params)
+        return {
+            "coarse_rgb_map": c_rgb, "coarse_depth_map": c_depth,
+            "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc,
+            "rgb_map": f_rgb, "depth_map": f_depth, "acc_map": f_acc,
+        }
+
     # ---- the reference's public surface ------------------------------------------------
     def render(self, batch, is_training: bool = True):
         return self.forward(batch, is_training)
@@ -96,9 +178,7 @@ class Renderer(nn.Module):
             raise NrfError(f"batch['xyz'] must be (1, R, 3) like the reference's classic path, got {tuple(xyz.shape)}")
         if not xyz.is_cuda:
             raise NrfError("batch tensors must be on a GPU: this renderer has no CPU path")
-        if torch.is_grad_enabled() and is_training and any(p.requires_grad for p in self.net.parameters()):
-            raise NotImplementedError("training (autograd) through the HIP renderer is not built yet: "
-                                      "call under torch.no_grad() for inference")
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
         dev = xyz.device
         rays_o = xyz[0].to(torch.float32).contiguous()
         rays_d = viewdirs[0].to(torch.float32).contiguous()
@@ -113,8 +193,9 @@ class Renderer(nn.Module):
         u = torch.rand((R, ni), device=dev)
         u2 = torch.rand(R, ni, device=dev)
         u_fine = torch.rand((R, ni), dtype=torch.float32, device=dev) if perturbed else None
-        out = self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
-        return out
+        if needs_grad:
+            return self.render_rays_train(rays_o, rays_d, u, u2, u_coarse, u_fine)
+        return self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
 
     def render_rays_staged(self, rays_o, rays_d, u, u2, u_coarse=None, u_fine=None, events=None):
         """Same kernels, same order as nrf_render, but one C-ABI call per stage so a profiler

@@ -1,0 +1,97 @@
+"""GPU parity of the training step's backward kernels against the reference's autograd results
+(tests/golden/train_camera32.npz) and against torch autograd on the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_composite_backward_vs_oracle_autograd(golden, dev):
+    from nerf_amd import ops
+    from oracle import nerf_oracle as O
+    for name, zkey, rkey in (("forward_camera64", "z_fine", "raw_fine"), ("forward_dense32", "t_bins", "raw_coarse"),
+                             ("forward_plumbing64", "z_fine", "raw_fine")):
+        fx = golden(name)
+        raw = torch.from_numpy(fx[rkey]).clone().requires_grad_(True)
+        R, S = raw.shape[0], raw.shape[1]
+        z = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(fx[zkey], (R, S))))
+        rgb, depth, w, acc = O.composite(raw, z, True)
+        g = torch.Generator().manual_seed(1)
+        g_rgb, g_depth, g_acc = torch.randn(R, 3, generator=g), torch.randn(R, generator=g), torch.randn(R, 1, generator=g)
+        ((rgb * g_rgb).sum() + (depth * g_depth).sum() + (acc * g_acc).sum()).backward()
+        got = ops.composite_backward(_t(fx[rkey], dev), _t(z.numpy(), dev), True, g_rgb.to(dev), g_depth.to(dev),
+                                     g_acc.to(dev)).cpu().numpy()
+        ref = raw.grad.numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), name
+
+
+def _setup(fx, dev):
+    from nerf_amd.network import Network
+    from nerf_amd.renderer import Renderer
+    from nerf_amd.weights import make_state_dict
+    from nerf_amd.config import default_cfg
+    net = Network()
+    net.load_state_dict(make_state_dict(int(fx["weight_seed"]), float(fx["density_gain"]), float(fx["density_bias"])))
+    net.to(dev)
+    r = Renderer(net, default_cfg(perturb=1))
+    r._bins = _t(fx["t_bins"], dev)
+    return net, r
+
+
+def test_training_step_gradients_match_reference(golden, dev):
+    fx = golden("train_camera32")
+    net, r = _setup(fx, dev)
+    out = r.render_rays_train(_t(fx["xyz"], dev), _t(fx["viewdirs"], dev), _t(fx["u"], dev), _t(fx["u2"], dev),
+                              _t(fx["u_coarse"], dev), _t(fx["u_fine"], dev))
+    gt = _t(fx["gt_rgb"], dev)
+    mse = torch.nn.MSELoss(reduction="mean")
+    loss = mse(out["coarse_rgb_map"], gt) + mse(out["fine_rgb_map"], gt)       # trainers/nerf.py:25-27
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5
+    loss.backward()
+    named = dict(net.named_parameters())
+    for n, ref in zip(list(fx["grad_names"]), fx["grad_norms"]):
+        got = float(named[n].grad.double().norm())
+        assert abs(got - ref) <= 2e-3 * max(ref, 1e-7), (n, got, ref)
+    for pre in ("model", "model_fine"):
+        m = getattr(net, pre)
+        checks = {
+            f"g.{pre}.alpha_linear.weight": m.alpha_linear.weight.grad,
+            f"g.{pre}.alpha_linear.bias": m.alpha_linear.bias.grad,
+            f"g.{pre}.rgb_linear.weight": m.rgb_linear.weight.grad,
+            f"g.{pre}.rgb_linear.bias": m.rgb_linear.bias.grad,
+            f"g.{pre}.pts_linears.0.bias": m.pts_linears[0].bias.grad,
+            f"g.{pre}.pts_linears.0.weight": m.pts_linears[0].weight.grad,
+            f"g.{pre}.pts_linears.5.weight[:, :72]": m.pts_linears[5].weight.grad[:, :72],
+            f"g.{pre}.pts_linears.7.weight[:8]": m.pts_linears[7].weight.grad[:8],
+            f"g.{pre}.views_linears.0.weight[:, 248:]": m.views_linears[0].weight.grad[:, 248:],
+            f"g.{pre}.feature_linear.bias": m.feature_linear.bias.grad,
+        }
+        for k, got in checks.items():
+            ref = fx[k]
+            err = float(np.abs(got.cpu().numpy() - ref).max())
+            assert err <= 2e-4 * max(float(np.abs(ref).max()), 1e-7), (k, err, float(np.abs(ref).max()))
+
+
+def test_renderer_forward_under_autograd_matches_inference(golden, dev):
+    fx = golden("train_camera32")
+    net, r = _setup(fx, dev)
+    args = (_t(fx["xyz"], dev), _t(fx["viewdirs"], dev), _t(fx["u"], dev), _t(fx["u2"], dev),
+            _t(fx["u_coarse"], dev), _t(fx["u_fine"], dev))
+    a = r.render_rays_train(*args)
+    with torch.no_grad():
+        b = r.render_rays(*args)
+    for k in ("coarse_rgb_map", "fine_rgb_map", "fine_depth_map", "alpha_map"):
+        assert torch.equal(a[k].detach(), b[k]), k
+    assert a["fine_rgb_map"].requires_grad
