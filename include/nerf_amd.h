@@ -146,6 +146,16 @@ int nrf_mlp_backward(const float* packed, const float* packed_t, const float* gr
                      const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace, int64_t workspace_bytes,
                      float* grad_flat, nrf_stream_t stream);
 
+/* grad[i] = 2 (x[i] - target[i]) / n: gradient of nn.MSELoss(mean) (src/train/trainers/nerf.py:25-27);
+ * if loss_accum is non-NULL, adds mean((x - target)^2) to *loss_accum (zero it first). */
+int nrf_mse_grad(const float* x, const float* target, int64_t n, float* grad, float* loss_accum, nrf_stream_t stream);
+
+/* clip_grad_value_(clip_value) then one torch.optim.Adam step (trainer.py:74-75, optimizer.py:9-29) over a
+ * flat buffer of n parameters; grads are first scaled by grad_scale (1/world after a sum all-reduce).
+ * `step` counts from 1. */
+int nrf_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float grad_scale,
+                  float clip_value, float lr, float beta1, float beta2, float eps, int step, nrf_stream_t stream);
+
 /* ---- whole forward path: volume_renderer.py:143-153 (render_coarse + render_fine) --- */
 
 typedef struct nrf_render_args {

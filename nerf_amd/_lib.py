@@ -18,7 +18,7 @@ SYMBOLS = (
     "nrf_sample_fine", "nrf_render_workspace_bytes", "nrf_render",
     "nrf_packed_bwd_floats", "nrf_pack_weights_transposed", "nrf_mlp_train_tiles", "nrf_mlp_acts_bytes",
     "nrf_mlp_masks_bytes", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_model_param_floats",
-    "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward",
+    "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mse_grad", "nrf_clip_adam",
 )
 
 P = C.c_void_p
@@ -78,6 +78,11 @@ def lib() -> C.CDLL:
     L.nrf_mlp_forward_rays_train.argtypes = [P, P, P, P, I64, I64, INT, P, P, P, P]
     L.nrf_composite_backward.argtypes = [P, P, I64, I64, INT, INT, P, P, P, P, P]
     L.nrf_mlp_backward.argtypes = [P, P, P, P, P, I64, INT, P, I64, P, P]
+    F = C.c_float
+    L.nrf_mse_grad.argtypes = [P, P, I64, P, P, P]
+    L.nrf_clip_adam.argtypes = [P, P, P, P, I64, F, F, F, F, F, F, INT, P]
+    L.nrf_mse_grad.restype = INT
+    L.nrf_clip_adam.restype = INT
     for name in ("nrf_pack_weights_transposed", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_mlp_backward"):
         getattr(L, name).restype = INT
     for name in ("nrf_pack_weights", "nrf_raygen", "nrf_perturb_samples", "nrf_mlp_forward_rays",

@@ -190,7 +190,8 @@ def composite_backward(raw, z, white_bkgd, g_rgb=None, g_depth=None, g_acc=None)
     return g_raw
 
 
-def mlp_backward(packed, packed_t, g_raw, acts, masks, workspace: torch.Tensor | None = None) -> torch.Tensor:
+def mlp_backward(packed, packed_t, g_raw, acts, masks, workspace: torch.Tensor | None = None,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
     """-> flat gradient (595,844,) of one model in state-dict order (weight then bias per layer)."""
     g_raw = _f32(g_raw, "g_raw")
     R, S = g_raw.shape[0], g_raw.shape[1]
@@ -199,7 +200,7 @@ def mlp_backward(packed, packed_t, g_raw, acts, masks, workspace: torch.Tensor |
     need = int(L.nrf_mlp_backward_workspace_bytes(R, S))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-    flat = torch.zeros(model_param_floats(), dtype=torch.float32, device=dev)
+    flat = torch.zeros(model_param_floats(), dtype=torch.float32, device=dev) if out is None else out
     with torch.cuda.device(dev):
         check(L.nrf_mlp_backward(_ptr(packed), _ptr(packed_t), _ptr(g_raw), _ptr(acts), _ptr(masks), R, S, _ptr(workspace),
                                  workspace.numel(), _ptr(flat), _stream(flat)), "nrf_mlp_backward")
@@ -216,3 +217,23 @@ def split_flat_grad(flat: torch.Tensor):
         o += fo
         out.append((w, b))
     return out
+
+
+def mse_grad(x: torch.Tensor, target: torch.Tensor, loss_accum: torch.Tensor | None = None) -> torch.Tensor:
+    x, target = _f32(x, "x"), _f32(target, "target")
+    assert x.numel() == target.numel()
+    g = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().nrf_mse_grad(_ptr(x), _ptr(target), x.numel(), _ptr(g), _ptr(loss_accum), _stream(x)), "nrf_mse_grad")
+    return g
+
+
+def clip_adam(params, grads, exp_avg, exp_avg_sq, step: int, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8,
+              clip_value=40.0, grad_scale=1.0) -> None:
+    """In-place on flat fp32 buffers (trainer.py:74-75 + optimizer.py:9-29 defaults)."""
+    for t in (params, grads, exp_avg, exp_avg_sq):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == params.numel()
+    with torch.cuda.device(params.device):
+        check(lib().nrf_clip_adam(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(),
+                                  float(grad_scale), float(clip_value), float(lr), float(beta1), float(beta2), float(eps),
+                                  int(step), _stream(params)), "nrf_clip_adam")

@@ -1,0 +1,92 @@
+"""One NeRF training step entirely on HIP kernels (BASELINE config 3).
+
+Semantics of the reference's step (src/train/trainers/trainer.py:68-75 with
+src/train/trainers/nerf.py:19-27 and src/train/optimizer.py:9-29): render coarse + fine with
+perturbed samples, ``loss = mse(coarse, gt) + mse(fine, gt)``, backward, gradient mean over
+ranks (DDP), ``clip_grad_value_(40)``, Adam(lr, 0.9, 0.999, 1e-8).
+
+MI355X shape: both models' parameters live in ONE flat fp32 buffer (the module's parameters are
+re-pointed at views of it, state-dict order), the backward writes ONE flat gradient buffer, so
+data parallelism is a single RCCL all-reduce of 4.77 MB per step and the optimizer is one fused
+kernel; the autograd route (``Renderer.render_rays_train``) stays available for callers that
+own their optimizer, like the reference trainer.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .renderer import near_far_table
+
+
+class TrainStep:
+    def __init__(self, net, device, near=2.0, far=6.0, n_coarse=64, n_importance=128, white_bkgd=True,
+                 lr=5e-4, clip_value=40.0, process_group=None):
+        self.net = net
+        self.device = torch.device(device)
+        self.n_coarse, self.n_importance, self.white = n_coarse, n_importance, bool(white_bkgd)
+        self.lr, self.clip = lr, clip_value
+        self.group = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        n = ops.model_param_floats()
+        self.flat = torch.empty(2 * n, dtype=torch.float32, device=self.device)
+        self.models = []
+        for k, name in enumerate(("model", "model_fine")):
+            model = getattr(net, name)
+            ws, bs = model.layer_params()
+            views = ops.split_flat_grad(self.flat[k * n:(k + 1) * n])
+            for (w, b), (vw, vb) in zip(zip(ws, bs), views):
+                vw.copy_(w.detach())
+                vb.copy_(b.detach())
+                w.data, b.data = vw, vb            # parameters now alias the flat buffer
+            self.models.append((ws, bs))
+        self.grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.t = 0
+        self.bins = torch.from_numpy(near_far_table(near, far, n_coarse)).to(self.device)
+        self._packed = [None, None]
+        self._packed_t = [None, None]
+        self._ws = None
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def _pack(self):
+        for k, (ws, bs) in enumerate(self.models):
+            self._packed[k] = ops.pack_weights(ws, bs, out=self._packed[k])
+            self._packed_t[k] = ops.pack_weights_transposed(ws, out=self._packed_t[k])
+
+    def forward_backward(self, rays_o, rays_d, gt, u, u2, u_coarse=None, u_fine=None):
+        """Fills self.grad (both models, flat) and self.loss; returns the render outputs."""
+        n = ops.model_param_floats()
+        self._pack()
+        pc, pf = self._packed
+        pc_t, pf_t = self._packed_t
+        zc = self.bins if u_coarse is None else ops.perturb_samples(self.bins, u_coarse)
+        raw_c, acts_c, masks_c = ops.mlp_forward_rays_train(pc, rays_o, rays_d, zc)
+        c_rgb, c_depth, w_c, _ = ops.composite(raw_c, zc, self.white, True)
+        z_f = ops.sample_fine(w_c, self.bins, zc, u, u2, u_fine)
+        raw_f, acts_f, masks_f = ops.mlp_forward_rays_train(pf, rays_o, rays_d, z_f)
+        f_rgb, f_depth, _, f_acc = ops.composite(raw_f, z_f, self.white, False)
+        self.loss.zero_()
+        g_c = ops.mse_grad(c_rgb, gt, self.loss)                     # trainers/nerf.py:25-27
+        g_f = ops.mse_grad(f_rgb, gt, self.loss)
+        need = int(ops.lib().nrf_mlp_backward_workspace_bytes(raw_f.shape[0], raw_f.shape[1]))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        g_raw_c = ops.composite_backward(raw_c, zc, self.white, g_c)
+        ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, self._ws, out=self.grad[:n])
+        del g_raw_c, acts_c, masks_c, raw_c
+        g_raw_f = ops.composite_backward(raw_f, z_f, self.white, g_f)
+        ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, self._ws, out=self.grad[n:])
+        return {"coarse_rgb_map": c_rgb, "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc}
+
+    def step(self, rays_o, rays_d, gt, u, u2, u_coarse=None, u_fine=None):
+        out = self.forward_backward(rays_o, rays_d, gt, u, u2, u_coarse, u_fine)
+        if self.world > 1:   # DDP semantics: mean of per-rank gradients; ONE flat sum all-reduce over RCCL
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        self.t += 1
+        ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.t, lr=self.lr, clip_value=self.clip,
+                      grad_scale=1.0 / self.world)
+        return out

@@ -95,3 +95,46 @@ def test_renderer_forward_under_autograd_matches_inference(golden, dev):
     for k in ("coarse_rgb_map", "fine_rgb_map", "fine_depth_map", "alpha_map"):
         assert torch.equal(a[k].detach(), b[k]), k
     assert a["fine_rgb_map"].requires_grad
+
+
+def test_fused_train_step_matches_reference_adam(golden, dev):
+    """TrainStep (flat buffers, fused clip + Adam) reproduces the reference's loss, gradients and the
+    parameters after one torch.optim.Adam step (tests/golden/train_camera32.npz `adam.*`)."""
+    from nerf_amd.network import Network
+    from nerf_amd.train import TrainStep
+    from nerf_amd.weights import make_state_dict
+    fx = golden("train_camera32")
+    net = Network()
+    net.load_state_dict(make_state_dict(int(fx["weight_seed"]), float(fx["density_gain"]), float(fx["density_bias"])))
+    net.to(dev)
+    ts = TrainStep(net, dev)
+    ts.bins = _t(fx["t_bins"], dev)
+    ts.step(_t(fx["xyz"], dev), _t(fx["viewdirs"], dev), _t(fx["gt_rgb"], dev), _t(fx["u"], dev), _t(fx["u2"], dev),
+            _t(fx["u_coarse"], dev), _t(fx["u_fine"], dev))
+    assert abs(float(ts.loss) - float(fx["loss"])) < 1e-5
+    for pre in ("model", "model_fine"):
+        m = getattr(net, pre)
+        for key, p in ((f"adam.{pre}.alpha_linear.weight", m.alpha_linear.weight),
+                       (f"adam.{pre}.pts_linears.0.bias", m.pts_linears[0].bias),
+                       (f"adam.{pre}.rgb_linear.weight", m.rgb_linear.weight)):
+            # first Adam step moves every parameter by ~lr * sign(g): compare the MOVE, not the value
+            err = np.abs(p.detach().cpu().numpy() - fx[key]).max()
+            assert err < 2e-5, (key, float(err))      # lr = 5e-4: 4 % of one step where g ~ eps-noise, else exact
+
+
+def test_clip_adam_matches_torch_over_steps(dev):
+    from nerf_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=5e-4, eps=1e-8, weight_decay=0.0)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (100.0 if step == 2 else 1.0)     # step 2 exercises the clip at 40
+        ref.grad = grad.clone()
+        torch.nn.utils.clip_grad_value_([ref], 40)
+        opt.step()
+        ops.clip_adam(p, grad.to(dev), m, v, step)
+        assert np.abs(p.cpu().numpy() - ref.detach().numpy()).max() < 2e-6, step
