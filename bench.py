@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", default="render", choices=["render", "train"],
+                    help="render: BASELINE configs[1] (default, the headline metric); train: configs[2], "
+                         "4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce")
+    ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -73,6 +77,69 @@ def cpu_baseline(seconds: float):
             "ms_per_frame_extrapolated": 1e3 * H * W * el / done}
 
 
+def train_bench(args, net, dev, rank, world, dist):
+    """BASELINE configs[2]: per rank 4096 random pixels of one view, perturb=1, fwd + 2xMSE + bwd +
+    gradient all-reduce (mean) + clip 40 + Adam(5e-4).  Weak scaling: every rank has its own batch."""
+    from nerf_amd import ops
+    from nerf_amd.camera import test_set_poses, focal_from_angle
+    from nerf_amd.train import TrainStep
+    ts = TrainStep(net, dev)
+    poses = test_set_poses(200)
+    focal = focal_from_angle(W)
+    R = args.train_rays
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+
+    def step(k):
+        pix = torch.randint(0, H * W, (R,), device=dev, generator=gen)
+        rays_o, rays_d = ops.raygen(poses[(k * world + rank) % len(poses)], H, W, focal, dev, pixel_index=pix)
+        gt = torch.rand((R, 3), device=dev, generator=gen)
+        u_c = torch.rand((R, N_COARSE), device=dev, generator=gen)
+        u = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
+        u2 = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
+        u_f = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
+        ts.step(rays_o, rays_d, gt, u, u2, u_c, u_f)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(ts.loss)
+    assert loss == loss
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        flop = 3.0 * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT   # fwd + dgrad + wgrad, SURVEY 8d
+        print(json.dumps({
+            "metric": "training rays/sec (fwd+bwd+Adam step, 64 coarse + 128 fine samples/ray)",
+            "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (random pixels of orbit views, random gt, random-init weights)",
+            "config": {"workload": "BASELINE configs[2]: NeRF training step, %d-ray batch per rank, fwd+bwd with Adam, "
+                                   "data-parallel RCCL all-reduce" % R, "rays_per_rank": R, "perturb": 1},
+            "roofline": {"kernel": "whole step (mlp_fwd<save> + mlp_dgrad + wgrad GEMMs)", "bound": "mfma",
+                         "achieved": flop / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "note": "algorithmic FLOPs of the step / wall time of the step, not one kernel"},
+            "final_loss": loss}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,6 +164,8 @@ def main():
     net = Network()
     net.load_state_dict(make_state_dict(0, 30.0, 2.0))   # random init, density rescaled so rays terminate
     net.to(dev)
+    if args.mode == "train":
+        return train_bench(args, net, dev, rank, world, dist)
     renderer = Renderer(net, default_cfg(perturb=0))
     poses = test_set_poses(200)
     focal = focal_from_angle(W)

@@ -148,12 +148,14 @@ struct WgradJob {
 
 constexpr int kLdsRow = 33;  // padded tile row: feature-on-lane operand reads hit 32 distinct banks
 
-// M = 32 * 4 * MB rows (waves split the row blocks), K = 32 * KB columns.
-template <int MB, int KB, bool HEAD>
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob job) {
-    constexpr int M = HEAD ? 32 : 128 * MB;
-    constexpr int K = HEAD ? 128 * KB : 32 * KB;  // HEAD: one row block, waves split the column blocks
-    constexpr int NACC = MB * KB;
+// One wave per 32-row block of dY (M = 32 * waves; 8 waves = 512 threads for the 256-row layers, so
+// two waves share each SIMD and cover each other's LDS latency), K = 32 * KB columns per wave.
+// HEAD: a single (zero-padded) row block, the 4 waves split the column blocks instead.
+template <int NW, int KB, bool HEAD>
+__global__ __launch_bounds__(NW * 64, NW / 4) void wgrad_kernel(WgradJob job) {
+    constexpr int NT = NW * 64;
+    constexpr int M = HEAD ? 32 : 32 * NW;
+    constexpr int K = HEAD ? 32 * NW * KB : 32 * KB;
     __shared__ float sA[M * kLdsRow];
     __shared__ float sB[K * kLdsRow];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,28 +165,28 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob job) {
     int64_t t1 = t0 + job.tiles_per_slice;
     if (t1 > job.n_tiles) t1 = job.n_tiles;
 
-    f32x16 acc[NACC];
+    f32x16 acc[KB];
 #pragma unroll
-    for (int a = 0; a < NACC; ++a)
+    for (int a = 0; a < KB; ++a)
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
     float bsum = 0.f;  // thread tid < M: row sum of dY row tid
 
     constexpr int A4 = M * 8, B4 = K * 8;  // float4 pieces per tile (32 floats = 8 float4 per row)
-    constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
+    constexpr int NA = (A4 + NT - 1) / NT, NB = (B4 + NT - 1) / NT;
     float4 ra[NA], rb[NB];
 
     auto load_tile = [&](int64_t tile) {
         const float4* pa = reinterpret_cast<const float4*>(job.a + (tile * job.a_stride + job.a_row0) * 32);
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
-            const int p = tid + 256 * n;
+            const int p = tid + NT * n;
             ra[n] = (p < A4 && (p >> 3) < job.a_rows) ? pa[p] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const float* xb = job.x + tile * job.x_stride * 32;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
-            const int p = tid + 256 * n;
+            const int p = tid + NT * n;
             const int row = p >> 3;
             if (p < B4) {
                 const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob job) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
-            const int p = tid + 256 * n;
+            const int p = tid + NT * n;
             if (p < A4) {
                 float* d = sA + (p >> 3) * kLdsRow + (p & 7) * 4;
                 d[0] = ra[n].x, d[1] = ra[n].y, d[2] = ra[n].z, d[3] = ra[n].w;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob job) {
         }
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
-            const int p = tid + 256 * n;
+            const int p = tid + NT * n;
             if (p < B4) {
                 float* d = sB + (p >> 3) * kLdsRow + (p & 7) * 4;
                 d[0] = rb[n].x, d[1] = rb[n].y, d[2] = rb[n].z, d[3] = rb[n].w;
@@ -222,32 +224,27 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradJob job) {
 #pragma unroll
             for (int p = 0; p < 32; ++p) bsum += r[p];
         }
-        const float* pa = sA + ((HEAD ? 0 : wave * MB * 32) + i) * kLdsRow + kh;
+        const float* pa = sA + ((HEAD ? 0 : wave * 32) + i) * kLdsRow + kh;
         const float* pb = sB + ((HEAD ? wave * KB * 32 : 0) + i) * kLdsRow + kh;
-#pragma unroll
+#pragma unroll 4
         for (int s = 0; s < 16; ++s) {  // 2 points per MFMA
-            float av[MB], bv[KB];
-#pragma unroll
-            for (int m = 0; m < MB; ++m) av[m] = pa[m * 32 * kLdsRow + 2 * s];
+            const float av = pa[2 * s];
+            float bv[KB];
 #pragma unroll
             for (int k = 0; k < KB; ++k) bv[k] = pb[k * 32 * kLdsRow + 2 * s];
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int k = 0; k < KB; ++k) acc[m * KB + k] = NRF_MFMA(av[m], bv[k], acc[m * KB + k]);
+            for (int k = 0; k < KB; ++k) acc[k] = NRF_MFMA(av, bv[k], acc[k]);
         }
     }
     // partial[slice][row][col]: 128 B contiguous per half-wave store
     float* out = job.partial + int64_t(slice) * M * K;
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int k = 0; k < KB; ++k) {
+        const int rb0 = HEAD ? 0 : wave * 32;
+        const int cb0 = HEAD ? (wave * KB + k) * 32 : k * 32;
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            const int rb0 = HEAD ? 0 : (wave * MB + m) * 32;
-            const int cb0 = HEAD ? (wave * KB + k) * 32 : k * 32;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) out[int64_t(rb0 + acc_row(t, kh)) * K + cb0 + i] = acc[m * KB + k][t];
-        }
+        for (int t = 0; t < 16; ++t) out[int64_t(rb0 + acc_row(t, kh)) * K + cb0 + i] = acc[k][t];
+    }
     if (tid < M) job.pbias[int64_t(slice) * M + tid] = bsum;
 }
 
@@ -278,6 +275,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
         const int col = map_col(cm, c);
         if (m < m_valid && col >= 0) {
             float s = 0.f;
+#pragma unroll 16
             for (int sl = 0; sl < n_slices; ++sl) s += partial[int64_t(sl) * M * K + idx];
             gw[int64_t(m) * ldw + col] = s;
         }
@@ -366,27 +364,27 @@ NRF_EXPORT int nrf_mlp_backward(const float* packed, const float* packed_t, cons
     };
     const dim3 grid(slices);
     // pts_linears.0: dY0 x encoding
-    wgrad_kernel<2, 2, false><<<grid, 256, 0, stream>>>(job(0, 256, kActPe, 64, 0, 0));
+    wgrad_kernel<8, 2, false><<<grid, 512, 0, stream>>>(job(0, 256, kActPe, 64, 0, 0));
     reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 0);
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {  // cat([encoding, h4]) (network.py:58)
-            wgrad_kernel<2, 10, false><<<grid, 256, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
+            wgrad_kernel<8, 10, false><<<grid, 512, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
             reduce(256, 320, 256, ColMap{{64, 256}, {10, 0}, {0, 63}}, 5);
         } else {
-            wgrad_kernel<2, 8, false><<<grid, 256, 0, stream>>>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0));
+            wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0));
             reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, l);
         }
     }
     // feature_linear: d feature x h7
-    wgrad_kernel<2, 8, false><<<grid, 256, 0, stream>>>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0));
+    wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0));
     reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, 8);
     // views_linears.0: dYv x cat([feature, dir encoding]) (network.py:63)
-    wgrad_kernel<1, 9, false><<<grid, 256, 0, stream>>>(job(kDyV, 128, kActFeat, 256, kActDpe, 32));
+    wgrad_kernel<4, 9, false><<<grid, 256, 0, stream>>>(job(kDyV, 128, kActFeat, 256, kActDpe, 32));
     reduce(128, 288, 128, ColMap{{256, 32}, {0, 4}, {0, 256}}, 10);
     // alpha_linear: d sigma (raw row 3) x h7;  rgb_linear: d rgb (raw rows 0..2) x hv
-    wgrad_kernel<1, 2, true><<<grid, 256, 0, stream>>>(job(kDyRaw + 3, 1, kActH + 7 * 256, 256, 0, 0));
+    wgrad_kernel<4, 2, true><<<grid, 256, 0, stream>>>(job(kDyRaw + 3, 1, kActH + 7 * 256, 256, 0, 0));
     reduce(32, 256, 1, ColMap{{256, 0}, {0, 0}, {0, 0}}, 9);
-    wgrad_kernel<1, 1, true><<<grid, 256, 0, stream>>>(job(kDyRaw, 3, kActHv, 128, 0, 0));
+    wgrad_kernel<4, 1, true><<<grid, 256, 0, stream>>>(job(kDyRaw, 3, kActHv, 128, 0, 0));
     reduce(32, 128, 3, ColMap{{128, 0}, {0, 0}, {0, 0}}, 11);
     return nrf_launch_status();
 }
