@@ -156,6 +156,44 @@ int nrf_mse_grad(const float* x, const float* target, int64_t n, float* grad, fl
 int nrf_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float grad_scale,
                   float clip_value, float lr, float beta1, float beta2, float eps, int step, nrf_stream_t stream);
 
+/* ---- KiloNeRF: src/models/kilonerf/network.py, src/models/kilonerf/renderer/volumn_renderer.py ---- */
+
+/* Per-cell MFMA streaming layout of the 12 batched tensors of BatchedKiloNeRF (network.py:87-113),
+ * `tensors_host`: HOST array of 12 DEVICE pointers in state-dict order: pts_linears_weights.0,
+ * pts_linears_biases.0, pts_linears_weights.1, pts_linears_biases.1, feature_linear_{weights,biases},
+ * sigma_linear_{weights,biases}, view_linears_{weights,biases}, rgb_linear_{weights,biases}. */
+int64_t nrf_kilo_packed_floats(int num_cells);
+int nrf_kilo_pack_weights(const float* const* tensors_host, int num_cells, float* packed, nrf_stream_t stream);
+
+/* Network._get_index + flat index (network.py:314-334, 246-253), bit-exact: cell[i] in [0, rx*ry*rz).
+ * aabb_host: {min xyz, max xyz}; res_host: {rx, ry, rz}. */
+int nrf_kilo_route(const float* pts, int64_t n, const float* aabb_host, const int* res_host, int32_t* cell,
+                   nrf_stream_t stream);
+
+/* Network.forward (network.py:223-311): route, counting-sort by cell, evaluate each point with its cell's
+ * tiny MLP; raw (n, 4) = [r, g, b, sigma] in input order.  dirs (n, 3) or, with dir_index (n,), (m, 3). */
+int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_cells);
+int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host, const float* pts,
+                     const float* dirs, const int32_t* dir_index, int64_t n_points, float* raw, void* workspace,
+                     int64_t workspace_bytes, nrf_stream_t stream);
+
+/* Occupancy-grid marching + early-ray-termination compositing: what volumn_renderer.py:78-86, 107-113 delegate
+ * to nerfacc (absent, unpinned).  This library's own rule: intervals [t0 + k*step, min(t0 + (k+1)*step, t1)) over
+ * the ray/box overlap clipped to [near, far], kept when the occupancy voxel (uint8 grid, (rx,ry,rz) C order) at the
+ * interval mid-point is non-zero; w_i = T_i * alpha_i while T_i >= ert_eps; depth = sum w t_mid / max(acc, eps). */
+int64_t nrf_kilo_march_workspace_bytes(int64_t n_rays);
+int nrf_kilo_march_count(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
+                         const int* occ_res_host, const float* aabb_host, float t_near, float t_far, float step,
+                         int32_t* counts, int32_t* offsets, int64_t* total, void* workspace, int64_t workspace_bytes,
+                         nrf_stream_t stream);
+int nrf_kilo_march_write(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
+                         const int* occ_res_host, const float* aabb_host, float t_near, float t_far, float step,
+                         const int32_t* offsets, float* pts, int32_t* ray_idx, float* t_start, float* t_end,
+                         nrf_stream_t stream);
+int nrf_kilo_composite(const float* raw, const float* t_start, const float* t_end, const int32_t* offsets,
+                       const int32_t* counts, int64_t n_rays, float ert_eps, int white_bkgd, float* rgb_map,
+                       float* depth_map, float* acc_map, nrf_stream_t stream);
+
 /* ---- whole forward path: volume_renderer.py:143-153 (render_coarse + render_fine) --- */
 
 typedef struct nrf_render_args {

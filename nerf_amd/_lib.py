@@ -19,6 +19,9 @@ SYMBOLS = (
     "nrf_packed_bwd_floats", "nrf_pack_weights_transposed", "nrf_mlp_train_tiles", "nrf_mlp_acts_bytes",
     "nrf_mlp_masks_bytes", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_model_param_floats",
     "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mse_grad", "nrf_clip_adam",
+    "nrf_kilo_packed_floats", "nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward_workspace_bytes",
+    "nrf_kilo_forward", "nrf_kilo_march_workspace_bytes", "nrf_kilo_march_count", "nrf_kilo_march_write",
+    "nrf_kilo_composite",
 )
 
 P = C.c_void_p
@@ -83,6 +86,21 @@ def lib() -> C.CDLL:
     L.nrf_clip_adam.argtypes = [P, P, P, P, I64, F, F, F, F, F, F, INT, P]
     L.nrf_mse_grad.restype = INT
     L.nrf_clip_adam.restype = INT
+    L.nrf_kilo_packed_floats.restype = I64
+    L.nrf_kilo_packed_floats.argtypes = [INT]
+    L.nrf_kilo_pack_weights.argtypes = [P, INT, P, P]
+    L.nrf_kilo_route.argtypes = [P, I64, P, P, P, P]
+    L.nrf_kilo_forward_workspace_bytes.restype = I64
+    L.nrf_kilo_forward_workspace_bytes.argtypes = [I64, INT]
+    L.nrf_kilo_forward.argtypes = [P, INT, P, P, P, P, P, I64, P, P, I64, P]
+    L.nrf_kilo_march_workspace_bytes.restype = I64
+    L.nrf_kilo_march_workspace_bytes.argtypes = [I64]
+    L.nrf_kilo_march_count.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, I64, P]
+    L.nrf_kilo_march_write.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, P, P]
+    L.nrf_kilo_composite.argtypes = [P, P, P, P, P, I64, F, INT, P, P, P, P]
+    for name in ("nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward", "nrf_kilo_march_count",
+                 "nrf_kilo_march_write", "nrf_kilo_composite"):
+        getattr(L, name).restype = INT
     for name in ("nrf_pack_weights_transposed", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_mlp_backward"):
         getattr(L, name).restype = INT
     for name in ("nrf_pack_weights", "nrf_raygen", "nrf_perturb_samples", "nrf_mlp_forward_rays",

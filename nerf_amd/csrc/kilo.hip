@@ -1,0 +1,563 @@
+// KiloNeRF: 16^3 tiny MLPs routed by cell, occupancy-grid ray marching, packed compositing.
+//
+// Replaces (reference paths): kilonerf/network.py:314-334 + :246-253 (_get_index, flat index),
+// :123-167 (BatchedKiloNeRF.forward: per point it gathers that point's full weight set,
+// 24.8 KB of HBM traffic per POINT, and does 1-row bmm's), :223-311 (Network.forward), and the
+// nerfacc calls of kilonerf/renderer/volumn_renderer.py:78-86, 107-113 (occupancy-grid sampling,
+// early ray termination, packed rendering).
+//
+// MI355X shape:
+//   * points are counting-sorted by cell (LDS histogram -> 4096-entry scan -> scatter), so a
+//     wavefront works on 32 points of ONE cell: the tiny MLP becomes 96 chained
+//     v_mfma_f32_32x32x2_f32 (same transposed register chain as the big MLP, one 32-row output
+//     block per layer) whose A operands -- the cell's whole weight set, 24 float4 per lane --
+//     are loaded ONCE per job and stay in registers for up to kJobTiles tiles;
+//   * ray marching is one wavefront per ray, 64 steps per iteration, ballot + popcount
+//     compaction, so the packed sample list is written in order without atomics;
+//   * packed compositing is the same wave scan as composite.hip over a ragged segment.
+// nerfacc is absent and unpinned: the sampling / termination / packed-rendering rules below
+// are this repo's own specification, checked against oracle/kilo_oracle.py.
+#include "mlp_chain.h"
+
+namespace {
+
+constexpr int kKiloSteps = 24;                 // float4-per-lane pieces of one cell's weights
+constexpr int kKiloSmall = 288;                // biases + heads, padded
+constexpr int kKiloCellFloats = kKiloSteps * 256 + kKiloSmall;  // 6432
+constexpr int kKOffBias = 0;                   // [4 layers: pts0, pts1, feature, view][h][16]
+constexpr int kKOffSigW = 128;                 // [h][16]
+constexpr int kKOffRgbW = 160;                 // [c][h][16]
+constexpr int kKOffSigB = 256, kKOffRgbB = 257;
+constexpr int kJobTiles = 16;                  // tiles of one cell handled per weight load
+
+struct KiloSrc {
+    const float* t[12];  // KILO tensor order: w0 b0 w1 b1 wf bf ws bs wv bv wr br, each (cells, ...)
+};
+
+__global__ void kilo_pack_kernel(KiloSrc s, int num_cells, float* __restrict__ packed) {
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= int64_t(num_cells) * kKiloCellFloats) return;
+    const int cell = int(gid / kKiloCellFloats), idx = int(gid - int64_t(cell) * kKiloCellFloats);
+    float v = 0.f;
+    if (idx < kKiloSteps * 256) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, step = idx >> 8;
+        const int h = lane >> 5, row = lane & 31, q = step & 3, t = 4 * q + e;
+        if (step < 8) {  // pts0: 63 encoding columns, kernel slot order
+            const int c = pe_col((step >> 2) * 16 + t, h, 10);
+            if (c >= 0) v = s.t[0][(int64_t(cell) * 32 + row) * 63 + c];
+        } else if (step < 12) {
+            v = s.t[2][(int64_t(cell) * 32 + row) * 32 + acc_row(t, h)];
+        } else if (step < 16) {
+            v = s.t[4][(int64_t(cell) * 32 + row) * 32 + acc_row(t, h)];
+        } else if (step < 20) {  // view layer, feature columns 0..31
+            v = s.t[8][(int64_t(cell) * 32 + row) * 59 + acc_row(t, h)];
+        } else {  // view layer, direction encoding columns 32..58
+            const int c = pe_col(t, h, 4);
+            if (c >= 0) v = s.t[8][(int64_t(cell) * 32 + row) * 59 + 32 + c];
+        }
+    } else {
+        const int i = idx - kKiloSteps * 256;
+        if (i < 128) {
+            const int layer = i >> 5, h = (i >> 4) & 1, r = i & 15;
+            const int src = layer == 0 ? 1 : layer == 1 ? 3 : layer == 2 ? 5 : 9;
+            v = s.t[src][int64_t(cell) * 32 + acc_row(r, h)];
+        } else if (i < 160) {
+            const int h = ((i - 128) >> 4) & 1, r = i & 15;
+            v = s.t[6][int64_t(cell) * 32 + acc_row(r, h)];
+        } else if (i < 256) {
+            const int j = i - 160, c = j >> 5, h = (j >> 4) & 1, r = j & 15;
+            v = s.t[10][(int64_t(cell) * 3 + c) * 32 + acc_row(r, h)];
+        } else if (i == kKOffSigB) {
+            v = s.t[7][cell];
+        } else if (i < kKOffRgbB + 3) {
+            v = s.t[11][int64_t(cell) * 3 + (i - kKOffRgbB)];
+        }
+    }
+    packed[gid] = v;
+}
+
+struct Grid {
+    float mn[3], mx[3];
+    int res[3];
+};
+
+// kilonerf/network.py:322-334, op for op in fp32: (p - min) / (max - min) * res, clamp(min=0),
+// min(res - 1), truncate.  Bit-exact (IEEE subtract / divide / multiply, no contraction).
+__device__ __forceinline__ int route_cell(const Grid& g, float x, float y, float z) {
+    const float p[3] = {x, y, z};
+    int idx[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float n = __fdiv_rn(__fsub_rn(p[a], g.mn[a]), __fsub_rn(g.mx[a], g.mn[a]));
+        float s = __fmul_rn(n, float(g.res[a]));
+        s = s < 0.f ? 0.f : s;                  // torch.clamp(min=0): NaN stays NaN -> (int) 0 below
+        const float hi = float(g.res[a]) - 1.0f;
+        s = s > hi ? hi : s;
+        idx[a] = int(s);
+        if (!(s == s)) idx[a] = 0;
+    }
+    return (idx[0] * g.res[1] + idx[1]) * g.res[2] + idx[2];  // :251-253
+}
+
+__global__ void kilo_route_kernel(Grid g, const float* __restrict__ pts, int64_t n, int* __restrict__ cell,
+                                  int* __restrict__ hist) {
+    extern __shared__ int s_hist[];
+    const int ncell = g.res[0] * g.res[1] * g.res[2];
+    if (hist)
+        for (int i = threadIdx.x; i < ncell; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const int c = route_cell(g, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
+        cell[i] = c;
+        if (hist) atomicAdd(&s_hist[c], 1);
+    }
+    __syncthreads();
+    if (hist)
+        for (int i = threadIdx.x; i < ncell; i += blockDim.x)
+            if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
+// single block: exclusive scan of the per-cell counts -> segment starts, cursors and the job prefix
+__global__ void kilo_cell_scan_kernel(const int* __restrict__ hist, int ncell, int* __restrict__ seg_start,
+                                      int* __restrict__ cursor, int* __restrict__ job_prefix) {
+    __shared__ int s_a[1024], s_b[1024];
+    const int tid = threadIdx.x;
+    const int per = (ncell + 1023) / 1024;
+    int cnt = 0, jobs = 0;
+    for (int k = 0; k < per; ++k) {
+        const int c = tid * per + k;
+        if (c < ncell) {
+            cnt += hist[c];
+            jobs += (hist[c] + 32 * kJobTiles - 1) / (32 * kJobTiles);
+        }
+    }
+    s_a[tid] = cnt, s_b[tid] = jobs;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int a = tid >= off ? s_a[tid - off] : 0, b = tid >= off ? s_b[tid - off] : 0;
+        __syncthreads();
+        s_a[tid] += a, s_b[tid] += b;
+        __syncthreads();
+    }
+    int a = s_a[tid] - cnt, b = s_b[tid] - jobs;  // exclusive
+    for (int k = 0; k < per; ++k) {
+        const int c = tid * per + k;
+        if (c < ncell) {
+            seg_start[c] = a, cursor[c] = a, job_prefix[c] = b;
+            a += hist[c];
+            b += (hist[c] + 32 * kJobTiles - 1) / (32 * kJobTiles);
+        }
+    }
+    if (tid == 1023) seg_start[ncell] = s_a[1023], job_prefix[ncell] = s_b[1023];
+}
+
+__global__ void kilo_scatter_kernel(const int* __restrict__ cell, int64_t n, int* __restrict__ cursor, int* __restrict__ perm) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        perm[atomicAdd(&cursor[cell[i]], 1)] = int(i);
+}
+
+// One 32x32 output block of a tiny layer: Y = init + sum_k W . x over NKB k-blocks of 32.
+template <int NKB>
+__device__ __forceinline__ f32x16 tiny_layer(const float4* w, f32x16 init, const f32x16* x) {
+    f32x16 y = init;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = w[kb * 4 + q];
+            y = NRF_MFMA(a.x, x[kb][4 * q + 0], y);
+            y = NRF_MFMA(a.y, x[kb][4 * q + 1], y);
+            y = NRF_MFMA(a.z, x[kb][4 * q + 2], y);
+            y = NRF_MFMA(a.w, x[kb][4 * q + 3], y);
+        }
+    return y;
+}
+
+// Persistent waves over jobs; job = up to kJobTiles 32-point tiles of one cell's sorted segment.
+__global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell,
+                                                          const int* __restrict__ seg_start,
+                                                          const int* __restrict__ job_prefix,
+                                                          const int* __restrict__ perm, const float* __restrict__ pts,
+                                                          const float* __restrict__ dirs,
+                                                          const int* __restrict__ dir_index, float4* __restrict__ raw) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    const int total_jobs = job_prefix[ncell];
+    for (int job = wave_global; job < total_jobs; job += n_waves) {
+        // cell of this job: last c with job_prefix[c] <= job
+        int lo = 0, hi = ncell;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (job_prefix[mid] <= job) lo = mid; else hi = mid;
+        }
+        const int cell = lo;
+        const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
+        const int first = seg_b + (job - job_prefix[cell]) * 32 * kJobTiles;
+        const float* cw = packed + int64_t(cell) * kKiloCellFloats;
+        float4 w[kKiloSteps];
+#pragma unroll
+        for (int s = 0; s < kKiloSteps; ++s) w[s] = reinterpret_cast<const float4*>(cw)[s * 64 + lane];
+        const float* sm = cw + kKiloSteps * 256;
+        f32x16 bias[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) bias[l] = *reinterpret_cast<const f32x16*>(sm + kKOffBias + l * 32 + h * 16);
+        const f32x16 sw = *reinterpret_cast<const f32x16*>(sm + kKOffSigW + h * 16);
+        f32x16 rw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rw[c] = *reinterpret_cast<const f32x16*>(sm + kKOffRgbW + c * 32 + h * 16);
+        const float sb = sm[kKOffSigB], rb0 = sm[kKOffRgbB], rb1 = sm[kKOffRgbB + 1], rb2 = sm[kKOffRgbB + 2];
+
+        for (int t0 = first; t0 < seg_e && t0 < first + 32 * kJobTiles; t0 += 32) {
+            const bool valid = t0 + j < seg_e;
+            const int id = perm[valid ? t0 + j : seg_e - 1];
+            const float px = pts[int64_t(id) * 3], py = pts[int64_t(id) * 3 + 1], pz = pts[int64_t(id) * 3 + 2];
+            const int64_t di = dir_index ? dir_index[id] : id;
+            const float dx = dirs[di * 3], dy = dirs[di * 3 + 1], dz = dirs[di * 3 + 2];
+            f32x16 pe[2], x[2];
+            pe[0] = encode_block<10, 0>(px, py, pz, h);
+            pe[1] = encode_block<10, 1>(px, py, pz, h);
+            const f32x16 dpe = encode_block<4, 0>(dx, dy, dz, h);
+            x[0] = relu16(tiny_layer<2>(w, bias[0], pe));                   // pts_linears 0 (network.py:132-138)
+            x[0] = relu16(tiny_layer<1>(w + 8, bias[1], x));                // pts_linears 1
+            float sigma = 0.f;                                              // sigma_linear (:142-144)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) sigma = fmaf(sw[t], x[0][t], sigma);
+            x[0] = tiny_layer<1>(w + 12, bias[2], x);                       // feature_linear (:147-149), no activation
+            x[1] = dpe;
+            const f32x16 hv = relu16(tiny_layer<2>(w + 16, bias[3], x));    // view_linears on cat([feature, dirs]) (:152-156)
+            float r = 0.f, g = 0.f, b = 0.f;                                // rgb_linear (:159-161)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                r = fmaf(rw[0][t], hv[t], r);
+                g = fmaf(rw[1][t], hv[t], g);
+                b = fmaf(rw[2][t], hv[t], b);
+            }
+            r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
+            if (h == 0 && valid) raw[id] = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
+        }
+    }
+}
+
+// ---- generic exclusive scan of int32 (three small kernels) ---------------------------------
+constexpr int kScanBlock = 1024;
+__global__ void scan_block_kernel(const int* __restrict__ in, int64_t n, int* __restrict__ out, int* __restrict__ sums) {
+    __shared__ int s[kScanBlock];
+    const int tid = threadIdx.x;
+    const int64_t i = int64_t(blockIdx.x) * kScanBlock + tid;
+    const int v = i < n ? in[i] : 0;
+    s[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        const int a = tid >= off ? s[tid - off] : 0;
+        __syncthreads();
+        s[tid] += a;
+        __syncthreads();
+    }
+    if (i < n) out[i] = s[tid] - v;
+    if (tid == kScanBlock - 1) sums[blockIdx.x] = s[tid];
+}
+__global__ void scan_sums_kernel(int* __restrict__ sums, int nblocks, int64_t* __restrict__ total) {
+    // single block, sequential over chunks of 1024 block sums
+    __shared__ int s[kScanBlock];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += kScanBlock) {
+        const int i = base + tid;
+        const int v = i < nblocks ? sums[i] : 0;
+        s[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < kScanBlock; off <<= 1) {
+            const int a = tid >= off ? s[tid - off] : 0;
+            __syncthreads();
+            s[tid] += a;
+            __syncthreads();
+        }
+        if (i < nblocks) sums[i] = carry + s[tid] - v;
+        __syncthreads();
+        if (tid == kScanBlock - 1) carry += s[tid];
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry;
+}
+__global__ void scan_add_kernel(int* __restrict__ out, int64_t n, const int* __restrict__ sums) {
+    const int64_t i = int64_t(blockIdx.x) * kScanBlock + threadIdx.x;
+    if (i < n) out[i] += sums[blockIdx.x];
+}
+
+// ---- occupancy-grid ray marching (own specification) ----------------
+struct March {
+    Grid g;          // scene box + occupancy resolution
+    float t_near, t_far, step;
+};
+
+// Interval k of a ray is [t0 + k*step, min(t0 + (k+1)*step, t1)) with [t0, t1] = ray-box overlap
+// clipped to [near, far]; it is kept when the occupancy voxel of its mid-point is set.
+__device__ __forceinline__ bool ray_box(const March& m, const float o[3], const float d[3], float& t0, float& t1) {
+    t0 = m.t_near, t1 = m.t_far;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = 1.0f / d[a];
+        float ta = (m.g.mn[a] - o[a]) * inv, tb = (m.g.mx[a] - o[a]) * inv;
+        if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+        if (d[a] == 0.f) {  // parallel to the slab: inside for all t or never
+            if (o[a] < m.g.mn[a] || o[a] > m.g.mx[a]) return false;
+            continue;
+        }
+        t0 = fmaxf(t0, ta), t1 = fminf(t1, tb);
+    }
+    return t0 < t1;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void kilo_march_kernel(March m, const float* __restrict__ rays_o,
+                                                         const float* __restrict__ rays_d, int64_t n_rays,
+                                                         const unsigned char* __restrict__ occ, int* __restrict__ counts,
+                                                         const int* __restrict__ offsets, float* __restrict__ pts,
+                                                         int* __restrict__ ray_idx, float* __restrict__ t_start,
+                                                         float* __restrict__ t_end) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2]};
+    const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
+    float t0, t1;
+    int count = 0;
+    if (ray_box(m, o, d, t0, t1)) {
+        const int nsteps = int(ceilf((t1 - t0) / m.step));
+        const int base = WRITE ? offsets[ray] : 0;
+        for (int k0 = 0; k0 < nsteps; k0 += 64) {
+            const int k = k0 + lane;
+            const float ts = t0 + float(k) * m.step;
+            const float te = fminf(ts + m.step, t1);
+            const float tm = 0.5f * (ts + te);
+            const float p[3] = {o[0] + d[0] * tm, o[1] + d[1] * tm, o[2] + d[2] * tm};
+            bool keep = k < nsteps && ts < t1;
+            if (keep) {
+                int v[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float s = (p[a] - m.g.mn[a]) / (m.g.mx[a] - m.g.mn[a]) * float(m.g.res[a]);
+                    v[a] = int(fminf(fmaxf(s, 0.f), float(m.g.res[a]) - 1.0f));
+                }
+                keep = occ[(int64_t(v[0]) * m.g.res[1] + v[1]) * m.g.res[2] + v[2]] != 0;
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (WRITE && keep) {
+                const int pos = base + count + __popcll(mask & ((1ull << lane) - 1ull));
+                pts[int64_t(pos) * 3] = p[0], pts[int64_t(pos) * 3 + 1] = p[1], pts[int64_t(pos) * 3 + 2] = p[2];
+                ray_idx[pos] = int(ray);
+                t_start[pos] = ts, t_end[pos] = te;
+            }
+            count += __popcll(mask);
+        }
+    }
+    if (!WRITE && lane == 0) counts[ray] = count;
+}
+
+// ---- packed compositing with early ray termination (own specification) -----------------------
+__global__ __launch_bounds__(256) void kilo_composite_kernel(const float4* __restrict__ raw, const float* __restrict__ t_start,
+                                                             const float* __restrict__ t_end,
+                                                             const int* __restrict__ offsets, const int* __restrict__ counts,
+                                                             int64_t n_rays, float ert_eps, int white_bkgd,
+                                                             float* __restrict__ rgb_map, float* __restrict__ depth_map,
+                                                             float* __restrict__ acc_map) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int base = offsets[ray], n = counts[ray];
+    float carry = 1.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f, sd = 0.f;
+    for (int c0 = 0; c0 < n && carry >= ert_eps; c0 += 64) {  // whole chunks past the threshold are skipped
+        const int s = c0 + lane;
+        const bool in = s < n;
+        const float4 rv = in ? raw[base + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ts = in ? t_start[base + s] : 0.f, te = in ? t_end[base + s] : 0.f;
+        const float alpha = in ? 1.f - expf(-fmaxf(rv.w, 0.f) * (te - ts)) : 0.f;  // volumn_renderer.py:99-100
+        float p = 1.f - alpha;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float t = __shfl_up(p, off);
+            if (lane >= off) p *= t;
+        }
+        float ex = __shfl_up(p, 1);
+        if (lane == 0) ex = 1.f;
+        const float T = carry * ex;
+        carry *= __shfl(p, 63);
+        const float w = T >= ert_eps ? T * alpha : 0.f;  // early ray termination: samples behind T < eps are dropped
+        sr += w / (1.f + expf(-rv.x));
+        sg += w / (1.f + expf(-rv.y));
+        sb += w / (1.f + expf(-rv.z));
+        sa += w;
+        sd += w * 0.5f * (ts + te);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sr += __shfl_xor(sr, off), sg += __shfl_xor(sg, off), sb += __shfl_xor(sb, off);
+        sa += __shfl_xor(sa, off), sd += __shfl_xor(sd, off);
+    }
+    if (lane == 0) {
+        const float bg = white_bkgd ? 1.f - sa : 0.f;  // volumn_renderer.py:116
+        rgb_map[ray * 3] = sr + bg, rgb_map[ray * 3 + 1] = sg + bg, rgb_map[ray * 3 + 2] = sb + bg;
+        depth_map[ray] = sd / fmaxf(sa, 1.1920929e-07f);
+        acc_map[ray] = sa;
+    }
+}
+
+Grid make_grid(const float* aabb, const int* res) {
+    Grid g;
+    for (int a = 0; a < 3; ++a) g.mn[a] = aabb[a], g.mx[a] = aabb[3 + a], g.res[a] = res[a];
+    return g;
+}
+
+inline int64_t a256(int64_t n) { return (n + 255) & ~int64_t(255); }
+
+}  // namespace
+
+NRF_EXPORT int64_t nrf_kilo_packed_floats(int num_cells) {
+    return num_cells <= 0 ? NRF_ERR_SHAPE : int64_t(num_cells) * kKiloCellFloats;
+}
+
+NRF_EXPORT int nrf_kilo_pack_weights(const float* const* tensors, int num_cells, float* packed, nrf_stream_t stream) {
+    if (!tensors || !packed) return NRF_ERR_NULL;
+    if (num_cells <= 0) return NRF_ERR_SHAPE;
+    KiloSrc s;
+    for (int i = 0; i < 12; ++i) {
+        if (!tensors[i]) return NRF_ERR_NULL;
+        s.t[i] = tensors[i];
+    }
+    if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
+    const int64_t total = int64_t(num_cells) * kKiloCellFloats;
+    nrf_launch_begin();
+    kilo_pack_kernel<<<dim3(unsigned((total + 255) / 256)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, packed);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_kilo_route(const float* pts, int64_t n, const float* aabb_host, const int* res_host, int32_t* cell,
+                              nrf_stream_t stream) {
+    if (n < 0) return NRF_ERR_SHAPE;
+    if (n == 0) return NRF_OK;
+    if (!pts || !aabb_host || !res_host || !cell) return NRF_ERR_NULL;
+    const Grid g = make_grid(aabb_host, res_host);
+    if (g.res[0] <= 0 || g.res[1] <= 0 || g.res[2] <= 0) return NRF_ERR_SHAPE;
+    const int64_t blocks = (n + 255) / 256;
+    nrf_launch_begin();
+    kilo_route_kernel<<<dim3(unsigned(blocks < 4096 ? blocks : 4096)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        g, pts, n, cell, nullptr);
+    return nrf_launch_status();
+}
+
+// workspace of nrf_kilo_forward: cell (n) | perm (n) | hist, seg_start, cursor, job_prefix (ncell + 1 each)
+NRF_EXPORT int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_cells) {
+    if (n_points < 0 || num_cells <= 0) return NRF_ERR_SHAPE;
+    return 2 * a256(n_points * 4) + 4 * a256((int64_t(num_cells) + 1) * 4);
+}
+
+// Network.forward (kilonerf/network.py:223-311) for a flat batch: raw[i] = [r, g, b, sigma] of point i
+// evaluated by the MLP of its cell.  dirs: (n, 3), or (m, 3) with dir_index (n,) int32 into it.
+NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host,
+                                const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
+                                float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream_) {
+    if (n_points < 0 || num_cells <= 0 || n_points > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    if (n_points == 0) return NRF_OK;
+    if (!packed || !aabb_host || !res_host || !pts || !dirs || !raw || !workspace) return NRF_ERR_NULL;
+    if (res_host[0] * res_host[1] * res_host[2] != num_cells || num_cells > 8192) return NRF_ERR_SHAPE;
+    if (workspace_bytes < nrf_kilo_forward_workspace_bytes(n_points, num_cells)) return NRF_ERR_WORKSPACE;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(raw) || !nrf_aligned16(workspace)) return NRF_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* wsb = static_cast<char*>(workspace);
+    int* cell = reinterpret_cast<int*>(wsb);
+    int* perm = reinterpret_cast<int*>(wsb + a256(n_points * 4));
+    const int64_t tab = a256((int64_t(num_cells) + 1) * 4);
+    int* hist = reinterpret_cast<int*>(wsb + 2 * a256(n_points * 4));
+    int* seg_start = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + tab);
+    int* cursor = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + 2 * tab);
+    int* job_prefix = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + 3 * tab);
+    const Grid g = make_grid(aabb_host, res_host);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    nrf_launch_begin();
+    (void)hipMemsetAsync(hist, 0, size_t(num_cells + 1) * 4, stream);
+    const int64_t blocks = (n_points + 255) / 256;
+    const unsigned rb = unsigned(blocks < 2048 ? blocks : 2048);
+    kilo_route_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(g, pts, n_points, cell, hist);
+    kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, seg_start, cursor, job_prefix);
+    kilo_scatter_kernel<<<dim3(rb), 256, 0, stream>>>(cell, n_points, cursor, perm);
+    kilo_mlp_kernel<<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, seg_start, job_prefix, perm, pts, dirs,
+                                                             dir_index, reinterpret_cast<float4*>(raw));
+    return nrf_launch_status();
+}
+
+// ---- rendering ------------------------------------------------------------------------------
+static int check_march(const float* rays_o, const float* rays_d, const unsigned char* occ, const float* aabb,
+                       const int* occ_res, float t_near, float t_far, float step) {
+    if (!rays_o || !rays_d || !occ || !aabb || !occ_res) return NRF_ERR_NULL;
+    if (!(step > 0.f) || !(t_far > t_near) || occ_res[0] <= 0 || occ_res[1] <= 0 || occ_res[2] <= 0) return NRF_ERR_SHAPE;
+    return NRF_OK;
+}
+
+// scan workspace: ceil(n/1024) ints
+NRF_EXPORT int64_t nrf_kilo_march_workspace_bytes(int64_t n_rays) {
+    return n_rays < 0 ? NRF_ERR_SHAPE : a256(((n_rays + kScanBlock - 1) / kScanBlock + 1) * 4);
+}
+
+// Pass 1: per-ray sample counts, their exclusive prefix (offsets) and the total (device int64).
+NRF_EXPORT int nrf_kilo_march_count(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
+                                    const int* occ_res_host, const float* aabb_host, float t_near, float t_far,
+                                    float step, int32_t* counts, int32_t* offsets, int64_t* total, void* workspace,
+                                    int64_t workspace_bytes, nrf_stream_t stream_) {
+    if (n_rays < 0) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (int st = check_march(rays_o, rays_d, occ, aabb_host, occ_res_host, t_near, t_far, step)) return st;
+    if (!counts || !offsets || !total || !workspace) return NRF_ERR_NULL;
+    if (workspace_bytes < nrf_kilo_march_workspace_bytes(n_rays)) return NRF_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    March m{make_grid(aabb_host, occ_res_host), t_near, t_far, step};
+    const int64_t blocks = (n_rays + 3) / 4;
+    if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    nrf_launch_begin();
+    kilo_march_kernel<false><<<dim3((unsigned)blocks), 256, 0, stream>>>(m, rays_o, rays_d, n_rays, occ, counts, nullptr,
+                                                                         nullptr, nullptr, nullptr, nullptr);
+    int* sums = static_cast<int*>(workspace);
+    const int nb = int((n_rays + kScanBlock - 1) / kScanBlock);
+    scan_block_kernel<<<nb, kScanBlock, 0, stream>>>(counts, n_rays, offsets, sums);
+    scan_sums_kernel<<<1, kScanBlock, 0, stream>>>(sums, nb, total);
+    scan_add_kernel<<<nb, kScanBlock, 0, stream>>>(offsets, n_rays, sums);
+    return nrf_launch_status();
+}
+
+// Pass 2: write the packed samples (mid-point positions, ray index, interval) in ray order.
+NRF_EXPORT int nrf_kilo_march_write(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
+                                    const int* occ_res_host, const float* aabb_host, float t_near, float t_far,
+                                    float step, const int32_t* offsets, float* pts, int32_t* ray_idx, float* t_start,
+                                    float* t_end, nrf_stream_t stream_) {
+    if (n_rays < 0) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (int st = check_march(rays_o, rays_d, occ, aabb_host, occ_res_host, t_near, t_far, step)) return st;
+    if (!offsets || !pts || !ray_idx || !t_start || !t_end) return NRF_ERR_NULL;
+    March m{make_grid(aabb_host, occ_res_host), t_near, t_far, step};
+    const int64_t blocks = (n_rays + 3) / 4;
+    if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    nrf_launch_begin();
+    kilo_march_kernel<true><<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream_)>>>(
+        m, rays_o, rays_d, n_rays, occ, nullptr, offsets, pts, ray_idx, t_start, t_end);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_kilo_composite(const float* raw, const float* t_start, const float* t_end, const int32_t* offsets,
+                                  const int32_t* counts, int64_t n_rays, float ert_eps, int white_bkgd, float* rgb_map,
+                                  float* depth_map, float* acc_map, nrf_stream_t stream) {
+    if (n_rays < 0) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (!offsets || !counts || !rgb_map || !depth_map || !acc_map) return NRF_ERR_NULL;
+    const int64_t blocks = (n_rays + 3) / 4;
+    if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    nrf_launch_begin();
+    kilo_composite_kernel<<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        reinterpret_cast<const float4*>(raw), t_start, t_end, offsets, counts, n_rays, ert_eps, white_bkgd, rgb_map,
+        depth_map, acc_map);
+    return nrf_launch_status();
+}

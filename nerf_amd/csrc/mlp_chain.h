@@ -102,12 +102,14 @@ __device__ __forceinline__ void ws_acquire(WeightStream& st, int lane) {
 }
 
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
+    // One v_max_i32 on the bit pattern: negative floats are negative ints (-> +0), non-negative ones order
+    // like ints.  fmaxf() costs a second, canonicalising v_max; an inline-asm v_max_f32 is invisible to the
+    // compiler's MFMA->VALU hazard pass and read stale registers right behind an MFMA chain.
     f32x16 r;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        float t;  // one v_max_f32 (fmaxf() costs a second, canonicalising v_max for signalling NaNs)
-        asm("v_max_f32 %0, 0, %1" : "=v"(t) : "v"(v[i]));
-        r[i] = t;
+        const int b = __float_as_int(v[i]);
+        r[i] = __int_as_float(b > 0 ? b : 0);
     }
     return r;
 }

@@ -1,0 +1,118 @@
+"""Tensor-level wrappers over the KiloNeRF entry points of the C ABI (include/nerf_amd.h, nrf_kilo_*).
+torch only owns the memory; all arithmetic happens in libnerf_amd.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import NrfError, check, lib
+from .ops import _f32, _ptr, _stream
+from .weights import KILO_TENSORS
+
+
+def _grid_args(aabb, res):
+    aabb = np.ascontiguousarray(np.asarray(aabb, dtype=np.float32).reshape(6))
+    res = np.ascontiguousarray(np.asarray(res, dtype=np.int32).reshape(3))
+    return aabb, res, aabb.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p)
+
+
+def kilo_pack_weights(tensors, out: torch.Tensor | None = None) -> torch.Tensor:
+    """12 batched (cells, ...) tensors in KILO_TENSORS order -> per-cell MFMA streaming layout."""
+    assert len(tensors) == 12
+    ts = [_f32(t.detach(), "kilo tensor") for t in tensors]
+    num_cells = ts[0].shape[0]
+    for t, (name, shape, _) in zip(ts, KILO_TENSORS):
+        if tuple(t.shape) != (num_cells,) + shape:
+            raise NrfError(f"{name}: shape {tuple(t.shape)}, want {(num_cells,) + shape} "
+                           "(only D=2, W=32 cells with 10/4-frequency encodings are supported)")
+    dev = ts[0].device
+    n = int(lib().nrf_kilo_packed_floats(num_cells))
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+    ptrs = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(dev):
+        check(lib().nrf_kilo_pack_weights(ptrs, num_cells, _ptr(out), _stream(out)), "nrf_kilo_pack_weights")
+    return out
+
+
+def kilo_pack_state_dict(sd: dict, device, prefix: str = "model.") -> torch.Tensor:
+    return kilo_pack_weights([torch.as_tensor(sd[prefix + n]).to(device=device, dtype=torch.float32)
+                              for n, _, _ in KILO_TENSORS])
+
+
+def kilo_route(pts: torch.Tensor, aabb, res) -> torch.Tensor:
+    pts = _f32(pts, "pts").reshape(-1, 3)
+    _a, _r, pa, pr = _grid_args(aabb, res)
+    cell = torch.empty(pts.shape[0], dtype=torch.int32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(lib().nrf_kilo_route(_ptr(pts), pts.shape[0], pa, pr, _ptr(cell), _stream(pts)), "nrf_kilo_route")
+    return cell
+
+
+def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, workspace=None) -> torch.Tensor:
+    """raw (n, 4) = [r, g, b, sigma] per point; dirs (n, 3) or (m, 3) with int32 dir_index (n,)."""
+    pts, dirs = _f32(pts, "pts").reshape(-1, 3), _f32(dirs, "dirs").reshape(-1, 3)
+    n = pts.shape[0]
+    if dir_index is None:
+        if dirs.shape[0] != n:
+            raise NrfError(f"dirs has {dirs.shape[0]} rows for {n} points and no dir_index")
+    else:
+        if dir_index.dtype != torch.int32 or dir_index.numel() != n or not dir_index.is_cuda:
+            raise NrfError("dir_index: expected int32 cuda tensor with one entry per point")
+        dir_index = dir_index.contiguous()
+    _a, _r, pa, pr = _grid_args(aabb, res)
+    raw = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
+    need = int(lib().nrf_kilo_forward_workspace_bytes(n, num_cells))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(lib().nrf_kilo_forward(_ptr(packed), num_cells, pa, pr, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,
+                                     _ptr(raw), _ptr(workspace), workspace.numel(), _stream(pts)), "nrf_kilo_forward")
+    return raw
+
+
+def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: float, step: float):
+    """Occupancy-grid marching.  Returns (pts (N,3), ray_idx (N,), t_start (N,), t_end (N,),
+    offsets (R,), counts (R,)); one host sync to learn N between the count and the write pass."""
+    rays_o, rays_d = _f32(rays_o, "rays_o").reshape(-1, 3), _f32(rays_d, "rays_d").reshape(-1, 3)
+    if occ.dtype != torch.uint8 or occ.ndim != 3 or not occ.is_cuda:
+        raise NrfError("occ: expected a 3-D uint8 cuda tensor")
+    occ = occ.contiguous()
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    _a, _r, pa, pr = _grid_args(aabb, occ.shape)
+    counts = torch.zeros(R, dtype=torch.int32, device=dev)
+    offsets = torch.zeros(R, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(int(lib().nrf_kilo_march_workspace_bytes(R)), 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().nrf_kilo_march_count(_ptr(rays_o), _ptr(rays_d), R, _ptr(occ), pr, pa, float(t_near), float(t_far),
+                                         float(step), _ptr(counts), _ptr(offsets), _ptr(total), _ptr(ws), ws.numel(),
+                                         _stream(rays_o)), "nrf_kilo_march_count")
+        n = int(total.item())
+        pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        ray_idx = torch.empty(n, dtype=torch.int32, device=dev)
+        t_start = torch.empty(n, dtype=torch.float32, device=dev)
+        t_end = torch.empty(n, dtype=torch.float32, device=dev)
+        if n:
+            check(lib().nrf_kilo_march_write(_ptr(rays_o), _ptr(rays_d), R, _ptr(occ), pr, pa, float(t_near),
+                                             float(t_far), float(step), _ptr(offsets), _ptr(pts), _ptr(ray_idx),
+                                             _ptr(t_start), _ptr(t_end), _stream(rays_o)), "nrf_kilo_march_write")
+    return pts, ray_idx, t_start, t_end, offsets, counts
+
+
+def kilo_composite(raw, t_start, t_end, offsets, counts, ert_eps: float, white_bkgd: bool):
+    R = offsets.shape[0]
+    dev = offsets.device
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((R,), dtype=torch.float32, device=dev)
+    acc = torch.empty((R,), dtype=torch.float32, device=dev)
+    if raw.shape[0]:
+        raw, t_start, t_end = _f32(raw, "raw"), _f32(t_start, "t_start"), _f32(t_end, "t_end")
+    with torch.cuda.device(dev):
+        check(lib().nrf_kilo_composite(_ptr(raw), _ptr(t_start), _ptr(t_end), _ptr(offsets), _ptr(counts), R,
+                                       float(ert_eps), int(bool(white_bkgd)), _ptr(rgb), _ptr(depth), _ptr(acc),
+                                       _stream(offsets)), "nrf_kilo_composite")
+    return rgb, depth, acc

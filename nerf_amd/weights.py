@@ -70,3 +70,34 @@ def make_state_dict(seed: int = 0, density_gain: float = 1.0, density_bias: floa
 
     return {k: torch.from_numpy(v.copy())
             for k, v in make_state_dict_arrays(seed, density_gain, density_bias).items()}
+
+
+# ---- KiloNeRF: 16^3 tiny MLPs as batched tensors ---------------------------------------------
+# (name, shape-after-the-cell-axis) in the reference's state-dict layout
+# (/root/reference/src/models/kilonerf/network.py:87-113), fan-in used for the uniform bound
+KILO_TENSORS = (
+    ("pts_linears_weights.0", (32, 63), 63), ("pts_linears_biases.0", (32,), 63),
+    ("pts_linears_weights.1", (32, 32), 32), ("pts_linears_biases.1", (32,), 32),
+    ("feature_linear_weights", (32, 32), 32), ("feature_linear_biases", (32,), 32),
+    ("sigma_linear_weights", (1, 32), 32), ("sigma_linear_biases", (1,), 32),
+    ("view_linears_weights", (32, 59), 59), ("view_linears_biases", (32,), 59),
+    ("rgb_linear_weights", (3, 32), 32), ("rgb_linear_biases", (3,), 32),
+)
+KILO_PARAMS_PER_CELL = sum(int(np.prod(s)) for _, s, _ in KILO_TENSORS)  # 6212
+
+
+def make_kilo_state_dict_arrays(seed: int = 0, num_cells: int = 4096, density_gain: float = 1.0,
+                                density_bias: float = 0.0) -> dict:
+    """Deterministic synthetic KiloNeRF weights: uniform(+-1/sqrt(fan_in)) per tensor, every cell
+    different; ``model.*`` keys as in the reference's ``Network.state_dict()`` (buffers excluded)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for name, shape, fan_in in KILO_TENSORS:
+        bound = 1.0 / np.sqrt(fan_in)
+        a = rng.uniform(-bound, bound, size=(num_cells,) + shape).astype(np.float32)
+        if name == "sigma_linear_weights":
+            a = (a * np.float32(density_gain)).astype(np.float32)
+        if name == "sigma_linear_biases":
+            a = (a * np.float32(density_gain) + np.float32(density_bias)).astype(np.float32)
+        sd["model." + name] = a
+    return sd

@@ -1,0 +1,163 @@
+"""GPU parity of the KiloNeRF entry points (nrf_kilo_*) through the C ABI.
+
+Routing is bit-exact against the reference fixture; the tiny-MLP outputs are checked against the
+reference fixture with the float64 yardstick; marching is bit-exact against the oracle's own rule
+and packed compositing within 1e-4 (those two rules are this repo's own: parity unpinned, see
+oracle/kilo_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+AABB = [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
+RES = [16, 16, 16]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _sd(seed=7, gain=20.0, bias=1.0):
+    from nerf_amd.weights import make_kilo_state_dict_arrays
+    return make_kilo_state_dict_arrays(seed, 4096, gain, bias)
+
+
+@pytest.fixture(scope="module")
+def packed(dev):
+    from nerf_amd import kilo_ops
+    return kilo_ops.kilo_pack_state_dict(_sd(), dev)
+
+
+def test_route_bit_exact(golden, dev):
+    from nerf_amd import kilo_ops
+    fx = golden("kilo_route")
+    cell = kilo_ops.kilo_route(_t(fx["pts"], dev), AABB, RES).cpu().numpy()
+    assert np.array_equal(cell.astype(np.int64), fx["flat"])
+
+
+def test_route_nan_inf_and_empty(dev):
+    from nerf_amd import kilo_ops
+    from oracle import kilo_oracle as K
+    p = np.array([[np.nan, 0, 0], [np.inf, -np.inf, 0.5], [1e30, -1e30, 0], [0, 0, 0]], dtype=np.float32)
+    cell = kilo_ops.kilo_route(_t(p, dev), AABB, RES).cpu().numpy()
+    assert np.array_equal(cell, K.route(p, AABB[:3], AABB[3:], RES)[1])
+    assert kilo_ops.kilo_route(torch.empty((0, 3), device=dev), AABB, RES).numel() == 0
+
+
+def _check(raw, ref, f64, tol):
+    err_ref = float(np.abs(ref - f64).max())
+    err_gpu = float(np.abs(raw - f64).max())
+    assert err_gpu <= max(3.0 * err_ref, tol), (err_gpu, err_ref)
+
+
+def test_tiny_mlp_matches_reference(golden, dev, packed):
+    from nerf_amd import kilo_ops
+    from oracle import kilo_oracle as K
+    fx = golden("kilo_network")
+    raw = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(fx["pts"], dev), _t(fx["dirs"], dev)).cpu().numpy()
+    ref = np.concatenate([fx["rgb"].reshape(-1, 3), fx["sigma"].reshape(-1, 1)], -1)
+    f64 = K.network_forward(_sd(), torch.from_numpy(fx["pts"]), torch.from_numpy(fx["dirs"]), AABB[:3], AABB[3:], RES,
+                            dtype=torch.float64).numpy()
+    _check(raw[:, :3], ref[:, :3], f64[:, :3], 2e-5)
+    _check(raw[:, 3], ref[:, 3], f64[:, 3], 2e-4)
+    # (R, S, 3) points with one direction per ray == dir_index form of the entry point
+    R, S = fx["rgb_rays"].shape[:2]
+    di = torch.arange(R, device=dev, dtype=torch.int32).repeat_interleave(S)
+    raw3 = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(fx["pts"][:R * S], dev), _t(fx["dirs"][:R], dev), di).cpu().numpy()
+    ref3 = np.concatenate([fx["rgb_rays"].reshape(-1, 3), fx["sigma_rays"].reshape(-1, 1)], -1)
+    assert np.abs(raw3[:, :3] - ref3[:, :3]).max() < 5e-5
+    assert np.abs(raw3[:, 3] - ref3[:, 3]).max() < 5e-4
+
+
+@pytest.mark.parametrize("n,spread", [(1, 1.0), (31, 1.0), (33, 0.02), (5000, 0.05), (200000, 1.2)])
+def test_tiny_mlp_matches_oracle_sizes(dev, packed, n, spread):
+    """Ragged tile tails, one hot cell (several jobs of one cell), all cells, points outside the box."""
+    from nerf_amd import kilo_ops
+    from oracle import kilo_oracle as K
+    rng = np.random.default_rng(n)
+    pts = (rng.uniform(-1, 1, size=(n, 3)) * spread + (0.31 if spread < 1 else 0.0)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    raw = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev)).cpu().numpy()
+    sub = slice(0, min(n, 20000))
+    ref = K.network_forward(_sd(), torch.from_numpy(pts[sub]), torch.from_numpy(dirs[sub]), AABB[:3], AABB[3:], RES).numpy()
+    f64 = K.network_forward(_sd(), torch.from_numpy(pts[sub]), torch.from_numpy(dirs[sub]), AABB[:3], AABB[3:], RES,
+                            dtype=torch.float64).numpy()
+    assert np.isfinite(raw).all()
+    _check(raw[sub, :3], ref[:, :3], f64[:, :3], 2e-5)
+    _check(raw[sub, 3], ref[:, 3], f64[:, 3], 2e-4)
+    # order independence: a permuted batch gives the permuted result, bit for bit
+    perm = rng.permutation(n)
+    raw_p = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts[perm], dev), _t(dirs[perm], dev)).cpu().numpy()
+    assert np.array_equal(raw_p, raw[perm])
+
+
+def _sphere_occ(n, radius=0.75):
+    c = (np.arange(n) + 0.5) / n * 2 - 1
+    x, y, z = np.meshgrid(c, c, c, indexing="ij")
+    return (np.sqrt(x * x + y * y + z * z) < radius).astype(np.uint8)
+
+
+def _camera_rays(n_side, seed=0):
+    from nerf_amd.camera import LEGO_CAMERA_ANGLE_X, pose_spherical
+    from oracle import nerf_oracle as O
+    c2w = pose_spherical(30.0 + seed, -30.0, 4.0)
+    o, d = O.raygen(c2w, n_side, n_side, LEGO_CAMERA_ANGLE_X)
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    return o.reshape(-1, 3).astype(np.float32), d.reshape(-1, 3).astype(np.float32)
+
+
+def test_march_bit_exact_vs_oracle(dev):
+    from nerf_amd import kilo_ops
+    from oracle import kilo_oracle as K
+    occ = _sphere_occ(64)
+    o, d = _camera_rays(40)
+    # add axis-parallel and missing rays
+    o = np.concatenate([o, [[0, 0, 4], [0.2, 5, 0.1], [3, 3, 3]]]).astype(np.float32)
+    d = np.concatenate([d, [[0, 0, -1], [0, -1, 0], [0, 0, 1]]]).astype(np.float32)
+    ref = K.march(o, d, occ, AABB[:3], AABB[3:], 2.0, 6.0, 0.005)
+    out = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), _t(occ, dev), AABB, 2.0, 6.0, 0.005)
+    names = ["pts", "ray_idx", "t_start", "t_end", "offsets", "counts"]
+    assert int(ref[5].sum()) > 10000
+    for nm, a, b in zip(names, out, ref):
+        assert np.array_equal(a.cpu().numpy(), b), nm
+
+
+def test_march_empty_grid_and_no_rays(dev):
+    from nerf_amd import kilo_ops
+    o, d = _camera_rays(8)
+    occ = np.zeros((16, 16, 16), dtype=np.uint8)
+    pts, ri, ts, te, off, cnt = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), _t(occ, dev), AABB, 2.0, 6.0, 0.01)
+    assert pts.shape == (0, 3) and int(cnt.sum()) == 0 and int(off.sum()) == 0
+    rgb, depth, acc = kilo_ops.kilo_composite(torch.empty((0, 4), device=dev), ts, te, off, cnt, 0.01, True)
+    assert torch.all(rgb == 1) and torch.all(acc == 0) and torch.all(depth == 0)
+    e = torch.empty((0, 3), device=dev)
+    out = kilo_ops.kilo_march(e, e, _t(occ, dev), AABB, 2.0, 6.0, 0.01)
+    assert out[0].shape == (0, 3) and out[4].numel() == 0
+
+
+@pytest.mark.parametrize("ert,white", [(0.0, True), (0.01, True), (0.01, False)])
+def test_composite_packed_vs_oracle(dev, ert, white):
+    from nerf_amd import kilo_ops
+    from oracle import kilo_oracle as K
+    rng = np.random.default_rng(5)
+    cnt = rng.integers(0, 300, size=500).astype(np.int32)
+    cnt[:4] = [0, 1, 64, 65]
+    off = (np.cumsum(cnt) - cnt).astype(np.int32)
+    n = int(cnt.sum())
+    raw = rng.normal(size=(n, 4)).astype(np.float32)
+    raw[:, 3] = (raw[:, 3] * 40 + 10).astype(np.float32)
+    ts = np.concatenate([2 + 0.005 * np.arange(c) for c in cnt]).astype(np.float32)
+    te = (ts + np.float32(0.005)).astype(np.float32)
+    rgb, depth, acc = kilo_ops.kilo_composite(_t(raw, dev), _t(ts, dev), _t(te, dev), _t(off, dev), _t(cnt, dev), ert, white)
+    r_rgb, r_depth, r_acc = K.composite_packed(raw, ts, te, off, cnt, ert, white)
+    assert np.abs(rgb.cpu().numpy() - r_rgb).max() < 1e-4
+    assert np.abs(acc.cpu().numpy() - r_acc).max() < 1e-4
+    assert np.abs(depth.cpu().numpy() - r_depth).max() < 1e-4 * 6

@@ -1,0 +1,84 @@
+"""KiloNeRF oracle against the fixtures made from the real reference (tools/gen_golden_kilo.py),
+plus CPU self-consistency of the own-spec (unpinned) marching / packed-compositing rules."""
+import numpy as np
+import torch
+
+from oracle import kilo_oracle as K
+from nerf_amd.weights import KILO_PARAMS_PER_CELL, make_kilo_state_dict_arrays
+
+AABB_MIN, AABB_MAX, RES = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], [16, 16, 16]
+
+
+def test_route_matches_reference_bit_exact(golden):
+    fx = golden("kilo_route")
+    idx3, flat = K.route(fx["pts"], AABB_MIN, AABB_MAX, RES)
+    assert np.array_equal(idx3, fx["index3"])
+    assert np.array_equal(flat, fx["flat"])
+    assert flat.min() == 0 and flat.max() == 4095
+
+
+def _sd(fx):
+    return make_kilo_state_dict_arrays(int(fx["weight_seed"]), 4096, float(fx["density_gain"]), float(fx["density_bias"]))
+
+
+def test_network_matches_reference(golden):
+    fx = golden("kilo_network")
+    sd = _sd(fx)
+    raw = K.network_forward(sd, torch.from_numpy(fx["pts"]), torch.from_numpy(fx["dirs"]), AABB_MIN, AABB_MAX, RES).numpy()
+    assert np.abs(raw[:, :3] - fx["rgb"].reshape(-1, 3)).max() < 2e-5
+    assert np.abs(raw[:, 3] - fx["sigma"].reshape(-1)).max() < 2e-4      # sigma head scaled by 20
+    R, S = fx["rgb_rays"].shape[:2]
+    raw3 = K.network_forward(sd, torch.from_numpy(fx["pts"][:R * S].reshape(R, S, 3)), torch.from_numpy(fx["dirs"][:R]),
+                             AABB_MIN, AABB_MAX, RES).numpy()
+    assert np.abs(raw3[:, :3] - fx["rgb_rays"].reshape(-1, 3)).max() < 2e-5
+    assert np.abs(raw3[:, 3] - fx["sigma_rays"].reshape(-1)).max() < 2e-4
+
+
+def test_color_reg_loss_matches_reference(golden):
+    fx = golden("kilo_network")
+    assert abs(K.color_reg_loss(_sd(fx)) - float(fx["color_reg_loss"])) < 1e-3 * float(fx["color_reg_loss"])
+    assert KILO_PARAMS_PER_CELL == 6212
+
+
+def _sphere_occ(n=32, radius=0.75):
+    c = (np.arange(n) + 0.5) / n * 2 - 1
+    x, y, z = np.meshgrid(c, c, c, indexing="ij")
+    return (np.sqrt(x * x + y * y + z * z) < radius).astype(np.uint8)
+
+
+def test_march_rules():
+    occ = _sphere_occ()
+    o = np.array([[0, 0, 4.0], [0, 0, 4.0], [3.0, 3.0, 3.0], [0.0, 0.0, 0.0]], dtype=np.float32)
+    d = np.array([[0, 0, -1.0], [0, 1.0, 0], [0, 0, -1.0], [0.6, 0.0, 0.8]], dtype=np.float32)
+    pts, ri, ts, te, off, cnt = K.march(o, d, occ, AABB_MIN, AABB_MAX, 2.0, 6.0, 0.01)
+    assert cnt[1] == 0 and cnt[2] == 0                       # misses the box
+    assert cnt[0] > 0 and off[0] == 0 and off[1] == cnt[0]
+    # ray 0 travels through the sphere along -z: samples are inside it, ordered, step-sized
+    assert np.all(np.linalg.norm(pts[:cnt[0]], axis=1) < 0.75 + 2.0 / 32 * np.sqrt(3))
+    assert np.all(np.diff(ts[:cnt[0]]) > 0)
+    assert np.all(te - ts <= 0.01 + 2e-6) and np.all(te > ts)
+    assert abs(cnt[0] * 0.01 - 1.5) < 0.15                   # chord of the voxelised sphere
+    # ray 3 starts inside the box: clipped to t >= near = 2 -> outside the box, nothing left
+    assert cnt[3] == 0
+    assert np.array_equal(ri, np.repeat(np.arange(4), cnt).astype(np.int32))
+
+
+def test_composite_packed_rules():
+    rng = np.random.default_rng(0)
+    cnt = np.array([5, 0, 70, 1], dtype=np.int32)
+    off = (np.cumsum(cnt) - cnt).astype(np.int32)
+    n = int(cnt.sum())
+    raw = rng.normal(size=(n, 4)).astype(np.float32)
+    raw[:, 3] = np.abs(raw[:, 3]) * 30
+    ts = np.concatenate([2 + 0.01 * np.arange(c) for c in cnt]).astype(np.float32)
+    te = (ts + np.float32(0.01)).astype(np.float32)
+    rgb, depth, acc = K.composite_packed(raw, ts, te, off, cnt, 0.0, True)
+    rgb0, depth0, acc0 = K.composite_packed(raw, ts, te, off, cnt, 0.01, True)
+    assert np.allclose(rgb[1], 1.0) and acc[1] == 0 and depth[1] == 0          # empty ray -> background
+    assert np.all(acc <= 1 + 1e-12) and np.all(acc0 <= acc + 1e-12)
+    assert np.all(acc - acc0 < 0.01 + 1e-12)                                   # ERT drops < eps of opacity
+    assert np.abs(rgb - rgb0).max() < 0.011
+    # single sample ray: closed form
+    a = 1 - np.exp(-max(raw[-1, 3], 0) * 0.01)
+    assert abs(acc[3] - a) < 1e-6
+    assert abs(depth[3] - 0.5 * (ts[-1] + te[-1])) < 1e-5

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the KiloNeRF rows from the REAL reference (build container only).
+
+Same recipe as tools/gen_golden.py with configs/kilonerf/lego.yaml (one config per process: the
+reference's cfg is a global built at import).  Covers what is pinned: cell routing
+(kilonerf/network.py:246-253, 314-334), the batched tiny MLPs (:123-167, :223-311) and the
+colour regulariser (:357-384).  Sampling / packed rendering live inside nerfacc (absent, version
+unpinned) and have no fixture.
+"""
+import os
+import sys
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+os.chdir(REF)
+sys.path.insert(0, REF)
+sys.argv = ["gen_golden_kilo", "--cfg_file", "configs/kilonerf/lego.yaml"]
+sys.modules["nerfacc"] = types.ModuleType("nerfacc")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from src.config import cfg  # noqa: E402,F401
+from src.models.kilonerf.network import Network  # noqa: E402
+
+from nerf_amd.weights import make_kilo_state_dict_arrays  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+net = Network()
+sd = {k: torch.from_numpy(v) for k, v in make_kilo_state_dict_arrays(7, 4096, 20.0, 1.0).items()}
+missing = net.load_state_dict(sd, strict=False)
+assert set(missing.missing_keys) <= {"aabb_min", "aabb_max", "grid_resolution"}, missing
+net.eval()
+
+g = torch.Generator().manual_seed(31)
+pts = (torch.rand(4000, 3, generator=g) * 2.6 - 1.3).float()          # inside and outside the [-1,1]^3 box
+special = torch.tensor([[-1, -1, -1], [1, 1, 1], [0, 0, 0], [0.999999, -0.999999, 0.125], [-1.5, 2.0, 0.3],
+                        [0.125, 0.25, 0.375], [-0.875, 0.875, -0.0625], [1.0, -1.0, 1.0],
+                        [np.nextafter(np.float32(0.125), np.float32(0)), 0.125, np.nextafter(np.float32(0.125), np.float32(1))]],
+                       dtype=torch.float32)
+# points on / next to every cell boundary along x
+edges = torch.linspace(-1, 1, 17)
+near_edges = torch.stack([torch.cat([edges, torch.nextafter(edges, torch.tensor(2.0)), torch.nextafter(edges, torch.tensor(-2.0))]),
+                          torch.zeros(51), torch.full((51,), 0.3)], -1).float()
+pts = torch.cat([pts, special, near_edges])
+with torch.no_grad():
+    idx3 = net._get_index(pts)
+    flat = idx3[:, 0] * 256 + idx3[:, 1] * 16 + idx3[:, 2]
+np.savez_compressed(os.path.join(OUT, "kilo_route.npz"), pts=pts.numpy(), index3=idx3.numpy(), flat=flat.numpy())
+print("kilo_route", pts.shape, int(flat.min()), int(flat.max()))
+
+P = 768
+p2 = (torch.rand(P, 3, generator=g) * 2 - 1).float()
+p2[:256] = p2[0] * 0.01 + torch.tensor([0.3, -0.4, 0.55]) + 0.05 * torch.rand(256, 3, generator=g)   # many points in few cells
+d2 = torch.randn(P, 3, generator=g).float()
+with torch.no_grad():
+    rgb, sigma = net(p2, d2)                       # (P,1,3), (P,1,1)
+    R, S = 24, 32
+    p3 = p2[: R * S].view(R, S, 3)
+    rgb3, sigma3 = net(p3, d2[:R])                 # dirs per ray
+    reg = net.get_color_reg_loss()
+np.savez_compressed(os.path.join(OUT, "kilo_network.npz"), pts=p2.numpy(), dirs=d2.numpy(), rgb=rgb.numpy(),
+                    sigma=sigma.numpy(), rgb_rays=rgb3.numpy(), sigma_rays=sigma3.numpy(), color_reg_loss=float(reg),
+                    weight_seed=7, density_gain=20.0, density_bias=1.0)
+print("kilo_network", rgb.shape, sigma.shape, float(reg), float(sigma.mean()))
