@@ -1,0 +1,158 @@
+"""KiloNeRF host side: ``KiloNetwork`` and ``KiloRenderer`` with the reference's interfaces.
+
+``KiloNetwork`` has the module tree / state-dict keys of
+/root/reference/src/models/kilonerf/network.py:172-220 (``model.pts_linears_weights.{0,1}``, ...,
+buffers ``aabb_min``, ``aabb_max``, ``grid_resolution``) and the ``forward(pts, viewdirs)`` signature of
+:223-311.  ``KiloRenderer`` is ``Renderer(net)`` of
+/root/reference/src/models/kilonerf/renderer/volumn_renderer.py:14-123: ``forward(batch, is_training)``
+returns ``rgb_map (B,R,3)``, ``depth_map (B,R,1)``, ``alpha_map (B,R,1)``.
+
+All arithmetic runs in libnerf_amd.so (nrf_kilo_*); there is no torch fallback.  Sampling, early
+termination and packed compositing follow this repository's own rule (the reference delegates them to
+nerfacc, which is absent and unpinned): see DESIGN.md section 7 and oracle/kilo_oracle.py.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import kilo_ops
+from .weights import KILO_TENSORS
+
+
+def default_kilo_cfg(**overrides) -> SimpleNamespace:
+    """The keys of /root/reference/configs/kilonerf/lego.yaml:26-67 this path reads."""
+    task = dict(white_bkgd=1, aabb={"min": [-1.0, -1.0, -1.0], "max": [1.0, 1.0, 1.0]}, grid_resolution=[16, 16, 16],
+                chunk_size=32768, l2_reg=1e-6)
+    sampler = dict(occ_factor=16, occ_threshold=10, ert_threshold=0.01, near=2, far=6, render_step_size=0.005)
+    for k, v in overrides.items():
+        (task if k in task else sampler)[k] = v
+    return SimpleNamespace(task_arg=SimpleNamespace(**task), sampler=SimpleNamespace(**sampler))
+
+
+class BatchedKiloNeRF(nn.Module):
+    """Parameter container with the reference's names and shapes (network.py:72-113, D=2, W=32)."""
+
+    def __init__(self, num_models: int):
+        super().__init__()
+        self.num_models = num_models
+        shapes = {n: s for n, s, _ in KILO_TENSORS}
+        mk = lambda n: nn.Parameter(torch.empty((num_models,) + shapes[n]))  # noqa: E731
+        self.pts_linears_weights = nn.ParameterList([mk("pts_linears_weights.0"), mk("pts_linears_weights.1")])
+        self.pts_linears_biases = nn.ParameterList([mk("pts_linears_biases.0"), mk("pts_linears_biases.1")])
+        for n in ("feature_linear", "sigma_linear", "view_linears", "rgb_linear"):
+            setattr(self, n + "_weights", mk(n + "_weights"))
+            setattr(self, n + "_biases", mk(n + "_biases"))
+        for p in self.parameters():  # network.py:117-121: kaiming_uniform(a=sqrt(5)) on every >1-D tensor
+            if p.dim() > 1:
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+            else:
+                nn.init.zeros_(p)
+
+    def tensors(self):
+        """The 12 tensors in include/nerf_amd.h order."""
+        out = []
+        for n, _, _ in KILO_TENSORS:
+            obj = self
+            for part in n.split("."):
+                obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+            out.append(obj)
+        return out
+
+
+class KiloNetwork(nn.Module):
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = cfg or default_kilo_cfg()
+        t = cfg.task_arg
+        self.register_buffer("aabb_min", torch.tensor(t.aabb["min"], dtype=torch.float32))
+        self.register_buffer("aabb_max", torch.tensor(t.aabb["max"], dtype=torch.float32))
+        self.register_buffer("grid_resolution", torch.tensor(t.grid_resolution, dtype=torch.long))
+        self._aabb = [float(v) for v in t.aabb["min"]] + [float(v) for v in t.aabb["max"]]
+        self._res = [int(v) for v in t.grid_resolution]
+        self.num_models = self._res[0] * self._res[1] * self._res[2]
+        self.white_bkgd = t.white_bkgd
+        self.model = BatchedKiloNeRF(self.num_models)
+        self._packed = None
+        self._packed_key = None
+
+    def grid(self):
+        return self._aabb, self._res
+
+    def packed(self) -> torch.Tensor:
+        """Per-cell streaming layout, repacked only when a parameter changed (tensor versions)."""
+        ts = self.model.tensors()
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if self._packed is None or key != self._packed_key or self._packed.device != ts[0].device:
+            self._packed = kilo_ops.kilo_pack_weights(ts, self._packed if self._packed is not None and
+                                                      self._packed.device == ts[0].device else None)
+            self._packed_key = key
+        return self._packed
+
+    @torch.no_grad()
+    def forward(self, pts, viewdirs):
+        """(R,S,3)+(R,3) or (P,3)+(P,3) -> rgb (R,S,3), sigma (R,S,1) raw (network.py:223-311)."""
+        if pts.ndim == 2:
+            R, S = pts.shape[0], 1
+            di = None
+        else:
+            R, S = pts.shape[:2]
+            di = torch.arange(R, device=pts.device, dtype=torch.int32).repeat_interleave(S)
+        raw = kilo_ops.kilo_forward(self.packed(), self.num_models, self._aabb, self._res, pts.reshape(-1, 3),
+                                    viewdirs, di).view(R, S, 4)
+        return raw[..., :3], raw[..., 3:4]
+
+    def get_color_reg_loss(self):
+        """network.py:357-384: plain torch on four parameter tensors (training-side, differentiable)."""
+        m = self.model
+        return (torch.sum(m.view_linears_weights ** 2) + torch.sum(m.view_linears_biases ** 2) +
+                torch.sum(m.rgb_linear_weights ** 2) + torch.sum(m.rgb_linear_biases ** 2))
+
+
+class KiloRenderer(nn.Module):
+    """``Renderer(net)`` for KiloNeRF.  ``occ_grid``: (rx,ry,rz) bool/uint8 tensor (the reference loads or bakes
+    it in ``__init__``, volumn_renderer.py:36-44; here it is handed in or set later with ``set_occ_grid``)."""
+
+    def __init__(self, net: KiloNetwork, cfg=None, occ_grid: torch.Tensor | None = None):
+        super().__init__()
+        self.net = net
+        cfg = cfg or default_kilo_cfg()
+        s = cfg.sampler
+        self.near, self.far = float(s.near), float(s.far)
+        self.step, self.ert = float(s.render_step_size), float(s.ert_threshold)
+        self.white_bkgd = bool(cfg.task_arg.white_bkgd)
+        self.occ_grid_resolution = [g * s.occ_factor for g in cfg.task_arg.grid_resolution]
+        self.occ_grid = None
+        self.last_num_samples = 0
+        if occ_grid is not None:
+            self.set_occ_grid(occ_grid)
+
+    def set_occ_grid(self, occ_grid: torch.Tensor):
+        if list(occ_grid.shape) != list(self.occ_grid_resolution):
+            raise ValueError(f"occupancy grid {tuple(occ_grid.shape)} != {self.occ_grid_resolution}")
+        self.occ_grid = occ_grid.to(torch.uint8).contiguous()
+
+    @torch.no_grad()
+    def forward(self, batch, is_training: bool = True):
+        if self.occ_grid is None:
+            raise RuntimeError("KiloRenderer: no occupancy grid (set_occ_grid)")
+        rays_o, viewdirs = batch["xyz"], batch["viewdirs"]
+        B, R, _ = rays_o.shape
+        o, d = rays_o.reshape(-1, 3), viewdirs.reshape(-1, 3)
+        aabb, res = self.net.grid()
+        occ = self.occ_grid if self.occ_grid.device == o.device else self.occ_grid.to(o.device)
+        self.occ_grid = occ
+        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, occ, aabb, self.near, self.far, self.step)
+        self.last_num_samples = int(pts.shape[0])
+        if pts.shape[0]:
+            raw = kilo_ops.kilo_forward(self.net.packed(), self.net.num_models, aabb, res, pts, d, ray_idx)
+        else:
+            raw = torch.empty((0, 4), dtype=torch.float32, device=o.device)
+        rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.ert, self.white_bkgd)
+        return {"rgb_map": rgb.view(B, R, 3), "depth_map": depth.view(B, R, 1), "alpha_map": acc.view(B, R, 1)}
+
+    def render(self, batch, is_training: bool = True):
+        return self.forward(batch, is_training)

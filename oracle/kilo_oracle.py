@@ -143,26 +143,31 @@ def march(rays_o: np.ndarray, rays_d: np.ndarray, occ: np.ndarray, aabb_min, aab
 # --------------------------------------------------------------------------------------
 # packed compositing with early ray termination -- own rule around volumn_renderer.py:89-122
 # --------------------------------------------------------------------------------------
-def composite_packed(raw: np.ndarray, t_start, t_end, offsets, counts, ert_eps: float, white_bkgd: bool):
+def composite_packed(raw: np.ndarray, t_start, t_end, offsets, counts, ert_eps: float, white_bkgd: bool,
+                     want_margin: bool = False):
     """alpha = 1 - exp(-relu(sigma) * (t_end - t_start)) (:99-100); rgb = sigmoid(raw rgb) (:97);
     T_i = prod_{j<i}(1 - alpha_j); w_i = T_i * alpha_i while T_i >= ert_eps, else 0 (the sample and
     everything behind it are terminated); colour = sum w rgb + (1 - acc) * white (:116);
-    depth = sum w t_mid / max(acc, fp32 eps); acc = sum w.  float64 accumulation (yardstick)."""
+    depth = sum w t_mid / max(acc, fp32 eps); acc = sum w.  float64 accumulation (yardstick).
+    ``want_margin`` also returns min_i |T_i - ert_eps| per ray: a ray whose margin is at fp32 rounding level
+    may legitimately terminate one sample earlier or later in an fp32 implementation."""
     raw = np.asarray(raw, dtype=np.float64).reshape(-1, 4)
     ts, te = np.asarray(t_start, dtype=np.float64), np.asarray(t_end, dtype=np.float64)
     R = len(offsets)
-    rgb, depth, acc = np.zeros((R, 3)), np.zeros(R), np.zeros(R)
+    rgb, depth, acc, margin = np.zeros((R, 3)), np.zeros(R), np.zeros(R), np.full(R, np.inf)
     for r in range(R):
         b, n = int(offsets[r]), int(counts[r])
         sl = slice(b, b + n)
         alpha = 1.0 - np.exp(-np.maximum(raw[sl, 3], 0.0) * (te[sl] - ts[sl]))
         T = np.concatenate([[1.0], np.cumprod(1.0 - alpha)[:-1]]) if n else np.zeros(0)
         w = np.where(T >= ert_eps, T * alpha, 0.0)
+        if n:
+            margin[r] = np.abs(T - ert_eps).min()
         c = 1.0 / (1.0 + np.exp(-raw[sl, :3]))
         acc[r] = w.sum()
         rgb[r] = (w[:, None] * c).sum(0) + ((1.0 - acc[r]) if white_bkgd else 0.0)
         depth[r] = (w * 0.5 * (ts[sl] + te[sl])).sum() / max(acc[r], float(np.finfo(np.float32).eps))
-    return rgb, depth, acc
+    return (rgb, depth, acc, margin) if want_margin else (rgb, depth, acc)
 
 
 def render(sd: dict, rays_o, rays_d, occ, aabb_min, aabb_max, res, t_near, t_far, step, ert_eps, white_bkgd):

@@ -161,3 +161,38 @@ def test_composite_packed_vs_oracle(dev, ert, white):
     assert np.abs(rgb.cpu().numpy() - r_rgb).max() < 1e-4
     assert np.abs(acc.cpu().numpy() - r_acc).max() < 1e-4
     assert np.abs(depth.cpu().numpy() - r_depth).max() < 1e-4 * 6
+
+
+def test_kilo_renderer_vs_oracle(dev):
+    """KiloRenderer(net)(batch) end to end (march -> route/sort -> tiny MLPs -> packed composite) against the
+    oracle's render on a 24x24 view of the sphere grid; un-normalised camera directions as the reference passes."""
+    from nerf_amd.camera import LEGO_CAMERA_ANGLE_X, pose_spherical
+    from nerf_amd.kilonerf import KiloNetwork, KiloRenderer, default_kilo_cfg
+    from oracle import kilo_oracle as K
+    from oracle import nerf_oracle as O
+    sd = _sd(3, 10.0, 0.5)
+    net = KiloNetwork()
+    missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert set(missing.missing_keys) <= {"aabb_min", "aabb_max", "grid_resolution"} and not missing.unexpected_keys
+    net = net.to(dev)
+    occ = _sphere_occ(256)
+    cfg = default_kilo_cfg()
+    r = KiloRenderer(net, cfg, _t(occ, dev))
+    o, d = O.raygen(pose_spherical(20.0, -30.0, 4.031), 24, 24, LEGO_CAMERA_ANGLE_X * 0.9)   # ~160 of 576 rays hit the sphere
+    o, d = o.reshape(-1, 3).astype(np.float32), d.reshape(-1, 3).astype(np.float32)
+    out = r({"xyz": _t(o, dev)[None], "viewdirs": _t(d, dev)[None]}, is_training=False)
+    ref = K.render(sd, o, d, occ, AABB[:3], AABB[3:], RES, 2.0, 6.0, 0.005, 0.01, True)
+    assert r.last_num_samples == ref["n_samples"] > 20000
+    assert out["rgb_map"].shape == (1, 576, 3) and out["depth_map"].shape == (1, 576, 1) and out["alpha_map"].shape == (1, 576, 1)
+    acc = ref["alpha_map"].reshape(-1)
+    assert (acc > 0.5).sum() > 50 and (acc == 0).sum() > 50 and ((acc > 0.2) & (acc < 0.8)).sum() > 50
+    for k in ("rgb_map", "alpha_map"):
+        assert np.abs(out[k].cpu().numpy() - ref[k]).max() < 1e-4, k
+    assert np.abs(out["depth_map"].cpu().numpy() - ref["depth_map"]).max() < 5e-4
+    # network.forward signature: (R,S,3) + (R,3) -> rgb (R,S,3), sigma (R,S,1)
+    p = torch.rand(6, 5, 3, device=dev) * 2 - 1
+    rgb, sigma = net(p, _t(d[:6], dev))
+    assert rgb.shape == (6, 5, 3) and sigma.shape == (6, 5, 1)
+    ref_raw = K.network_forward(sd, p.cpu(), torch.from_numpy(d[:6]), AABB[:3], AABB[3:], RES).numpy()
+    assert np.abs(torch.cat([rgb, sigma], -1).reshape(-1, 4).cpu().numpy() - ref_raw).max() < 1e-3
+    assert abs(float(net.get_color_reg_loss()) - K.color_reg_loss(sd)) < 1e-3 * K.color_reg_loss(sd)
