@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", default="render", choices=["render", "train"],
+    ap.add_argument("--mode", default="render", choices=["render", "train", "kilo"],
                     help="render: BASELINE configs[1] (default, the headline metric); train: configs[2], "
-                         "4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce")
+                         "4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce; kilo: configs[3], KiloNeRF "
+                         "800x800 frame with the sphere occupancy grid")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -140,6 +141,90 @@ def train_bench(args, net, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def kilo_bench(args, dev, rank, world, dist):
+    """BASELINE configs[3]: KiloNeRF, 4096 cells (W=32, D=2), occupancy = sphere |x| < 0.75 at 256^3, step 0.005,
+    ERT 0.01, near 2 / far 6, 800x800 view per rank per step (weak scaling, no data-path collective)."""
+    from nerf_amd import kilo_ops, ops
+    from nerf_amd.camera import test_set_poses, focal_from_angle
+    from nerf_amd.kilonerf import KiloNetwork, KiloRenderer, default_kilo_cfg
+    from nerf_amd.weights import make_kilo_state_dict_arrays
+    net = KiloNetwork()
+    sd = make_kilo_state_dict_arrays(0, 4096, 10.0, 0.5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net.to(dev)
+    c = (torch.arange(256, device=dev, dtype=torch.float32) + 0.5) / 256 * 2 - 1
+    occ = ((c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2).sqrt() < 0.75).to(torch.uint8)
+    r = KiloRenderer(net, default_kilo_cfg(), occ)
+    poses = test_set_poses(200)
+    focal = focal_from_angle(W)
+    R = H * W
+    aabb, res = net.grid()
+    packed = net.packed()
+    ev = {k: [] for k in ("march", "mlp", "composite")}
+
+    def E():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(dev))
+        return e
+
+    samples = []
+
+    def step(k, timed):
+        rays_o, rays_d = ops.raygen(poses[(k * world + rank) % len(poses)], H, W, focal, dev)
+        e0 = E()
+        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(rays_o, rays_d, r.occ_grid, aabb, r.near, r.far, r.step)
+        e1 = E()
+        raw = kilo_ops.kilo_forward(packed, net.num_models, aabb, res, pts, rays_d, ray_idx)
+        e2 = E()
+        out = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, r.ert, True)
+        e3 = E()
+        if timed:
+            ev["march"].append((e0, e1)), ev["mlp"].append((e1, e2)), ev["composite"].append((e2, e3))
+            samples.append(int(pts.shape[0]))
+        return out
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        out = step(k, False)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = step(args.warmup + k, True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out[0]).all()
+    if rank == 0:
+        ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+        n = float(np.mean(samples))
+        flop = 12160.0 * n                                    # SURVEY 8a row 14: 6080 MACs per evaluated sample
+        print(json.dumps({
+            "metric": "rays/sec (KiloNeRF 800x800 frame, occupancy-grid marching + early termination)",
+            "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (orbit camera, random-init cells, sigma head x10 + 0.5, sphere occupancy)",
+            "config": {"workload": "BASELINE configs[3]: KiloNeRF 16^3 cells W=32 D=2, sphere |x|<0.75 occupancy at 256^3, "
+                                   "step 0.005, ERT 0.01, 800x800 view per rank per step", "rays_per_frame": R,
+                       "samples_per_frame": n, "samples_per_hit_ray": n / max(1.0, float((out[2] > 0).sum()))},
+            "roofline": {"kernel": "kilo_forward (route + counting sort + kilo_mlp_kernel)", "bound": "mfma",
+                         "achieved": flop / (ms["mlp"] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "samples_per_s": n / (ms["mlp"] * 1e-3)},
+            "stage_ms": ms}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,6 +246,8 @@ def main():
     from nerf_amd.renderer import Renderer
     from nerf_amd.weights import make_state_dict
 
+    if args.mode == "kilo":
+        return kilo_bench(args, dev, rank, world, dist)
     net = Network()
     net.load_state_dict(make_state_dict(0, 30.0, 2.0))   # random init, density rescaled so rays terminate
     net.to(dev)

@@ -151,11 +151,34 @@ __global__ void kilo_cell_scan_kernel(const int* __restrict__ hist, int ncell, i
     if (tid == 1023) seg_start[ncell] = s_a[1023], job_prefix[ncell] = s_b[1023];
 }
 
-__global__ void kilo_scatter_kernel(const int* __restrict__ cell, int64_t n, int* __restrict__ cursor, int* __restrict__ perm) {
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-        perm[atomicAdd(&cursor[cell[i]], 1)] = int(i);
+// Counting-sort scatter.  Consecutive points are consecutive samples of one ray and stay in a cell for ~25
+// steps, so per-point atomics on cursor[cell] collide 64-wide; instead each run of equal cells inside a
+// wavefront takes ONE atomic for the whole run (its head lane) and the lanes of the run fan out behind it.
+__global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict__ cell, int64_t n, int* __restrict__ cursor,
+                                                           int* __restrict__ perm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t rounds = (n + stride - 1) / stride;  // every lane runs every round: shuffles need full waves
+    for (int64_t k = 0; k < rounds; ++k) {
+        const int64_t i = k * stride + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+        const bool in = i < n;
+        const int c = in ? cell[i] : -1;
+        const int prev = __shfl_up(c, 1);
+        const bool head = lane == 0 || c != prev;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int head_lane = 63 - __clzll(upto);                       // last head at or before this lane
+        const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+        const int next_head = after ? __ffsll((long long)after) - 1 : 64;  // first head after this lane
+        int base = 0;
+        if (head && in) base = atomicAdd(&cursor[c], next_head - lane);
+        base = __shfl(base, head_lane);
+        if (in) perm[base + (lane - head_lane)] = int(i);
+    }
 }
 
+// One 32x32 output block of a tiny layer: Y = init + sum_k W . x over NKB k-blocks of 32.  `gap(m)` is called
+// behind MFMA number BASE + i of the tile with work to run in that MFMA's shadow.
 // One 32x32 output block of a tiny layer: Y = init + sum_k W . x over NKB k-blocks of 32.
 template <int NKB>
 __device__ __forceinline__ f32x16 tiny_layer(const float4* w, f32x16 init, const f32x16* x) {
@@ -174,6 +197,14 @@ __device__ __forceinline__ f32x16 tiny_layer(const float4* w, f32x16 init, const
 }
 
 // Persistent waves over jobs; job = up to kJobTiles 32-point tiles of one cell's sorted segment.
+//
+// What bounds it (measured): on gfx950 the f32 MFMA runs at the vector-ALU rate (64 cycles per
+// 32x32x2; 157 TF is also the VALU peak) and VALU work does not hide under it: ablations show tile time = its 96
+// MFMAs (6.1k cycles) PLUS its ~1200 VALU instructions (sin/cos encoding ~950 of them, ~4.7 cycles each).
+// Hand-interleaving the next tile's encoding into the MFMA gaps, and two waves per SIMD, both measured no faster,
+// so this is the plain form: one wave per SIMD, the cell's whole weight set in registers for the job (24 float4 of
+// matrix operands, biases as accumulator initialisers, head rows), gathers prefetched three tiles ahead.
+template <bool INDEXED>  // directions gathered through dir_index (one per ray) or given per point
 __global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell,
                                                           const int* __restrict__ seg_start,
                                                           const int* __restrict__ job_prefix,
@@ -209,23 +240,47 @@ __global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restric
         for (int c = 0; c < 3; ++c) rw[c] = *reinterpret_cast<const f32x16*>(sm + kKOffRgbW + c * 32 + h * 16);
         const float sb = sm[kKOffSigB], rb0 = sm[kKOffRgbB], rb1 = sm[kKOffRgbB + 1], rb2 = sm[kKOffRgbB + 2];
 
+        // Gather pipeline: perm -> (point, dir index) -> direction is three dependent loads; indices run three
+        // tiles ahead, points two, directions one.  Reads past the job's last tile are clamped to the segment's
+        // last element (valid memory, results unused).  32-bit element offsets: n_points <= 2^28 (host check).
+        const int last = seg_e - 1;
+        auto tile_id = [&](int t0) { const int k = t0 + j; return unsigned(perm[unsigned(k < last ? k : last)]); };
+        auto dir_of = [&](unsigned id) { return INDEXED ? unsigned(dir_index[id]) : id; };  // no branch in the tile loop
+        unsigned id_c = tile_id(first), id_n = tile_id(first + 32), id_nn = tile_id(first + 64);
+        float pc[3], pn[3], dc[3];
+        unsigned di_n;
+        {
+            const unsigned di_c = dir_of(id_c);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pc[a] = pts[id_c * 3u + a], dc[a] = dirs[di_c * 3u + a];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pn[a] = pts[id_n * 3u + a];
+            di_n = dir_of(id_n);
+        }
         for (int t0 = first; t0 < seg_e && t0 < first + 32 * kJobTiles; t0 += 32) {
             const bool valid = t0 + j < seg_e;
-            const int id = perm[valid ? t0 + j : seg_e - 1];
-            const float px = pts[int64_t(id) * 3], py = pts[int64_t(id) * 3 + 1], pz = pts[int64_t(id) * 3 + 2];
-            const int64_t di = dir_index ? dir_index[id] : id;
-            const float dx = dirs[di * 3], dy = dirs[di * 3 + 1], dz = dirs[di * 3 + 2];
-            f32x16 pe[2], x[2];
-            pe[0] = encode_block<10, 0>(px, py, pz, h);
-            pe[1] = encode_block<10, 1>(px, py, pz, h);
-            const f32x16 dpe = encode_block<4, 0>(dx, dy, dz, h);
-            x[0] = relu16(tiny_layer<2>(w, bias[0], pe));                   // pts_linears 0 (network.py:132-138)
+            const unsigned id = id_c;
+            const float px = pc[0], py = pc[1], pz = pc[2], dx = dc[0], dy = dc[1], dz = dc[2];
+            {   // issue the loads of the following tiles, rotate the pipeline registers
+                float dn[3], pnn[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) dn[a] = dirs[di_n * 3u + a], pnn[a] = pts[id_nn * 3u + a];
+                const unsigned di_nn = dir_of(id_nn);
+                const unsigned id_nnn = tile_id(t0 + 96);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pc[a] = pn[a], dc[a] = dn[a], pn[a] = pnn[a];
+                id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_n = di_nn;
+            }
+            f32x16 x[2];
+            x[0] = encode_block<10, 0>(px, py, pz, h);
+            x[1] = encode_block<10, 1>(px, py, pz, h);
+            x[0] = relu16(tiny_layer<2>(w, bias[0], x));                    // pts_linears 0 (network.py:132-138)
             x[0] = relu16(tiny_layer<1>(w + 8, bias[1], x));                // pts_linears 1
             float sigma = 0.f;                                              // sigma_linear (:142-144)
 #pragma unroll
             for (int t = 0; t < 16; ++t) sigma = fmaf(sw[t], x[0][t], sigma);
             x[0] = tiny_layer<1>(w + 12, bias[2], x);                       // feature_linear (:147-149), no activation
-            x[1] = dpe;
+            x[1] = encode_block<4, 0>(dx, dy, dz, h);
             const f32x16 hv = relu16(tiny_layer<2>(w + 16, bias[3], x));    // view_linears on cat([feature, dirs]) (:152-156)
             float r = 0.f, g = 0.f, b = 0.f;                                // rgb_linear (:159-161)
 #pragma unroll
@@ -460,7 +515,7 @@ NRF_EXPORT int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_ce
 NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host,
                                 const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
                                 float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream_) {
-    if (n_points < 0 || num_cells <= 0 || n_points > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    if (n_points < 0 || num_cells <= 0 || n_points > (1LL << 28)) return NRF_ERR_SHAPE;  // 32-bit byte offsets in the kernels
     if (n_points == 0) return NRF_OK;
     if (!packed || !aabb_host || !res_host || !pts || !dirs || !raw || !workspace) return NRF_ERR_NULL;
     if (res_host[0] * res_host[1] * res_host[2] != num_cells || num_cells > 8192) return NRF_ERR_SHAPE;
@@ -486,8 +541,12 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
     kilo_route_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(g, pts, n_points, cell, hist);
     kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, seg_start, cursor, job_prefix);
     kilo_scatter_kernel<<<dim3(rb), 256, 0, stream>>>(cell, n_points, cursor, perm);
-    kilo_mlp_kernel<<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, seg_start, job_prefix, perm, pts, dirs,
-                                                             dir_index, reinterpret_cast<float4*>(raw));
+    if (dir_index)
+        kilo_mlp_kernel<true><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, seg_start, job_prefix, perm, pts,
+                                                                       dirs, dir_index, reinterpret_cast<float4*>(raw));
+    else
+        kilo_mlp_kernel<false><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, seg_start, job_prefix, perm, pts,
+                                                                        dirs, dir_index, reinterpret_cast<float4*>(raw));
     return nrf_launch_status();
 }
 

@@ -239,20 +239,32 @@ __device__ __forceinline__ f32x16 mask16(f32x16 v, unsigned bits) {
 // 3-term pi/2 (valid for |a| < 2^17, i.e. |x| < 256 at the 2^9 band; the scene lives in
 // |x| <= far = 6) and degree-7/8 minimax polynomials: max abs error 9.2e-8 over |a| <= 2e4
 // (tests/test_host_logic.py emulates it; torch's own sin is within 7e-8 of exact).
-__device__ __forceinline__ float sin_or_cos(float a, int h) {
-    const float k = rintf(a * 0.63661977236758134308f);
-    float r = fmaf(k, __uint_as_float(0xbfc90fdau), a);  // -1.570796251296997
-    r = fmaf(k, __uint_as_float(0xb3a22168u), r);        // -7.549789415861596e-08
-    r = fmaf(k, __uint_as_float(0xa7c234c4u), r);        // -5.390302529957765e-15
+// Split in two so a caller can place the halves in different gaps of an MFMA chain (kilo.hip).
+struct TrigReduced {
+    float k, r, z, sp, cp;  // quadrant, reduced argument, its square, inner parts of the sin / cos polynomials
+};
+__device__ __forceinline__ TrigReduced trig_reduce(float a) {
+    TrigReduced t;
+    t.k = rintf(a * 0.63661977236758134308f);
+    float r = fmaf(t.k, __uint_as_float(0xbfc90fdau), a);  // -1.570796251296997
+    r = fmaf(t.k, __uint_as_float(0xb3a22168u), r);        // -7.549789415861596e-08
+    r = fmaf(t.k, __uint_as_float(0xa7c234c4u), r);        // -5.390302529957765e-15
+    t.r = r;
     const float z = r * r;
-    float sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
-    sp = fmaf(sp * z, r, r);
-    float cp = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-    cp = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
-    const int q = int(k) + h;  // cos(a) = sin(a + pi/2)
+    t.z = z;
+    t.sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    t.cp = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    return t;
+}
+__device__ __forceinline__ float trig_finish(TrigReduced t, int h) {
+    const float r = t.r, z = t.z;
+    const float sp = fmaf(t.sp * z, r, r);
+    const float cp = fmaf(t.cp * z, z, fmaf(-0.5f, z, 1.0f));
+    const int q = int(t.k) + h;  // cos(a) = sin(a + pi/2)
     const float v = (q & 1) ? cp : sp;
     return (q & 2) ? -v : v;
 }
+__device__ __forceinline__ float sin_or_cos(float a, int h) { return trig_finish(trig_reduce(a), h); }
 
 // 16 encoding slots of one k-block: trig part for slots n < 3L, then the raw inputs.
 template <int L, int KB>
