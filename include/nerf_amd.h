@@ -194,6 +194,15 @@ int nrf_kilo_composite(const float* raw, const float* t_start, const float* t_en
                        const int32_t* counts, int64_t n_rays, float ert_eps, int white_bkgd, float* rgb_map,
                        float* depth_map, float* acc_map, nrf_stream_t stream);
 
+/* Occupancy-grid bake from the teacher NeRF: Renderer._evaluate_grid (kilonerf/renderer/volumn_renderer.py:142-232).
+ * For cells [first_cell, first_cell + n_cells) of the (rx,ry,rz) grid (C order): 27 sub-points per cell (:169-176,
+ * :194) through the teacher's packed fine MLP with zero view directions (:204-207); occ[cell] = any raw sigma >
+ * threshold (:212-220).  `occ` points at the whole grid (uint8, rx*ry*rz). */
+int64_t nrf_occ_bake_workspace_bytes(int64_t n_cells);
+int nrf_occ_bake(const float* packed_teacher, const float* aabb_host, const int* res_host, float threshold,
+                 int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
+                 nrf_stream_t stream);
+
 /* ---- whole forward path: volume_renderer.py:143-153 (render_coarse + render_fine) --- */
 
 typedef struct nrf_render_args {

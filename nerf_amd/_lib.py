@@ -21,7 +21,7 @@ SYMBOLS = (
     "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mse_grad", "nrf_clip_adam",
     "nrf_kilo_packed_floats", "nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward_workspace_bytes",
     "nrf_kilo_forward", "nrf_kilo_march_workspace_bytes", "nrf_kilo_march_count", "nrf_kilo_march_write",
-    "nrf_kilo_composite",
+    "nrf_kilo_composite", "nrf_occ_bake_workspace_bytes", "nrf_occ_bake",
 )
 
 P = C.c_void_p
@@ -86,6 +86,10 @@ def lib() -> C.CDLL:
     L.nrf_clip_adam.argtypes = [P, P, P, P, I64, F, F, F, F, F, F, INT, P]
     L.nrf_mse_grad.restype = INT
     L.nrf_clip_adam.restype = INT
+    L.nrf_occ_bake_workspace_bytes.restype = I64
+    L.nrf_occ_bake_workspace_bytes.argtypes = [I64]
+    L.nrf_occ_bake.restype = INT
+    L.nrf_occ_bake.argtypes = [P, P, P, F, I64, I64, P, P, I64, P]
     L.nrf_kilo_packed_floats.restype = I64
     L.nrf_kilo_packed_floats.argtypes = [INT]
     L.nrf_kilo_pack_weights.argtypes = [P, INT, P, P]

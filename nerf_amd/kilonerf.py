@@ -112,6 +112,13 @@ class KiloNetwork(nn.Module):
                 torch.sum(m.rgb_linear_weights ** 2) + torch.sum(m.rgb_linear_biases ** 2))
 
 
+def _ref_layer_params(model):
+    """Weights / biases of a reference-style NeRF module in include/nerf_amd.h order."""
+    from .ops import LAYER_NAMES
+    sd = dict(model.named_parameters())
+    return [sd[n + ".weight"] for n in LAYER_NAMES], [sd[n + ".bias"] for n in LAYER_NAMES]
+
+
 class KiloRenderer(nn.Module):
     """``Renderer(net)`` for KiloNeRF.  ``occ_grid``: (rx,ry,rz) bool/uint8 tensor (the reference loads or bakes
     it in ``__init__``, volumn_renderer.py:36-44; here it is handed in or set later with ``set_occ_grid``)."""
@@ -134,6 +141,28 @@ class KiloRenderer(nn.Module):
         if list(occ_grid.shape) != list(self.occ_grid_resolution):
             raise ValueError(f"occupancy grid {tuple(occ_grid.shape)} != {self.occ_grid_resolution}")
         self.occ_grid = occ_grid.to(torch.uint8).contiguous()
+
+    def grid_filename(self, occ_threshold) -> str:
+        """The reference's cache file name (volumn_renderer.py:37-38)."""
+        r = self.occ_grid_resolution
+        return f"occ_grid_res{r[0]}_{r[1]}_{r[2]}_thresh{occ_threshold}.pth"
+
+    @torch.no_grad()
+    def bake_occ_grid(self, teacher, occ_threshold: float = 10.0, chunk_cells: int = 1 << 20):
+        """`_evaluate_grid` (volumn_renderer.py:142-232): `teacher` is the NeRF `Network` (its fine model is queried)."""
+        from . import ops
+        ws, bs = teacher.model_fine.layer_params() if hasattr(teacher.model_fine, "layer_params") else _ref_layer_params(
+            teacher.model_fine)
+        packed = ops.pack_weights(ws, bs)
+        aabb, _ = self.net.grid()
+        self.set_occ_grid(kilo_ops.occ_bake(packed, aabb, self.occ_grid_resolution, occ_threshold, chunk_cells))
+        return self.occ_grid
+
+    def save_occ_grid(self, path: str):
+        torch.save(self.occ_grid.bool().cpu(), path)      # the reference's format: a (rx,ry,rz) bool tensor (:126-132)
+
+    def load_occ_grid(self, path: str, device=None):
+        self.set_occ_grid(torch.load(path, map_location=device or "cpu", weights_only=True))
 
     @torch.no_grad()
     def forward(self, batch, is_training: bool = True):

@@ -183,3 +183,31 @@ def render(sd: dict, rays_o, rays_d, occ, aabb_min, aabb_max, res, t_near, t_far
     R = len(off)
     return {"rgb_map": rgb.reshape(1, R, 3).astype(F32), "depth_map": depth.reshape(1, R, 1).astype(F32),
             "alpha_map": acc.reshape(1, R, 1).astype(F32), "n_samples": int(cnt.sum())}
+
+
+# --------------------------------------------------------------------------------------
+# occupancy-grid bake -- volumn_renderer.py:142-232 (`_evaluate_grid`), restated with the same torch ops
+# --------------------------------------------------------------------------------------
+def bake_points(aabb_min, aabb_max, res) -> torch.Tensor:
+    """The (cells, 27, 3) evaluation points: linspace cell corners + cell_size / 2 (:156-164), offsets
+    {-0.25, 0, 0.25}^3 * cell_size in meshgrid 'ij' order (:170-176), centre + offset (:194)."""
+    mn, mx = torch.tensor(aabb_min, dtype=torch.float32), torch.tensor(aabb_max, dtype=torch.float32)
+    resf = torch.tensor(res, dtype=torch.float32)
+    cell = (mx - mn) / resf
+    axes = [torch.linspace(float(mn[a]), float(mx[a]), res[a] + 1)[:-1] for a in range(3)]
+    gx, gy, gz = torch.meshgrid(*axes, indexing="ij")
+    centres = torch.stack([gx, gy, gz], -1) + cell / 2.0
+    o = torch.tensor([-0.25, 0.0, 0.25])
+    offs = torch.stack(torch.meshgrid([o, o, o], indexing="ij"), -1).view(-1, 3) * cell
+    return centres.view(-1, 1, 3) + offs[None]
+
+
+def bake(teacher_sd: dict, aabb_min, aabb_max, res, threshold: float, want_sigma: bool = False):
+    """Teacher fine-model raw sigma at the 27 points, zero view directions (:204-207); occupied = any > threshold
+    (:212-220).  Returns the (rx,ry,rz) bool grid (and the (cells, 27) sigmas)."""
+    from .nerf_oracle import network_forward as nerf_forward
+    pts = bake_points(aabb_min, aabb_max, res).reshape(-1, 3)
+    raw = nerf_forward(teacher_sd, pts, torch.zeros_like(pts), "fine")
+    sig = raw[:, 3].reshape(-1, 27)
+    occ = (sig > threshold).any(-1).reshape(*res)
+    return (occ.numpy(), sig.numpy()) if want_sigma else occ.numpy()

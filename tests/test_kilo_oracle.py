@@ -82,3 +82,15 @@ def test_composite_packed_rules():
     a = 1 - np.exp(-max(raw[-1, 3], 0) * 0.01)
     assert abs(acc[3] - a) < 1e-6
     assert abs(depth[3] - 0.5 * (ts[-1] + te[-1])) < 1e-5
+
+
+def test_bake_points_layout():
+    """_evaluate_grid's points: cell order C (i,j,k), 27 offsets in meshgrid 'ij' order, centre = corner + cell/2."""
+    pts = K.bake_points(AABB_MIN, AABB_MAX, [4, 2, 8]).numpy()
+    assert pts.shape == (64, 27, 3)
+    cell = np.array([0.5, 1.0, 0.25], dtype=np.float32)
+    assert np.allclose(pts[0, 13], np.array([-1, -1, -1]) + cell / 2)            # sub-point 13 = the centre
+    assert np.allclose(pts[0, 0], pts[0, 13] - 0.25 * cell) and np.allclose(pts[0, 26], pts[0, 13] + 0.25 * cell)
+    assert np.allclose(pts[1, 13] - pts[0, 13], [0, 0, 0.25])                     # k is the fastest cell index
+    assert np.allclose(pts[0, 1] - pts[0, 0], [0, 0, 0.25 * 0.25])                # z offset is the fastest sub index
+    assert np.allclose(pts[63, 13], np.array([1, 1, 1]) - cell / 2)
