@@ -53,6 +53,18 @@ def parse():
     return ap.parse_args()
 
 
+def recorded_traffic():
+    """HBM bytes per mlp_fwd_kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_mlp_traffic_pmc.json: FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md corrections).  Counters cannot
+    be read from inside the process, so this is the recorded figure, or None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_mlp_traffic_pmc.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["traffic_bytes_per_launch_mean"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds: float):
     """Oracle render of 1024-ray slices of the bench view until ~`seconds` of CPU time."""
     from oracle import nerf_oracle as O
@@ -317,7 +329,10 @@ def main():
                        "n_importance": N_IMPORTANCE, "sharding": f"views round-robin over {world} rank(s)"},
             "roofline": {"kernel": "mlp_fwd_kernel<true> (fused points + PE + 8x256 MLP, fp32 MFMA)",
                          "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": recorded_traffic(),
+                         "traffic_note": "HBM bytes per launch (mean of coarse + fine) from profiles/r01_mlp_traffic_pmc.json; "
+                                         "algorithmic bytes per launch %.4g" % (0.5 * R * ((N_COARSE + N_COARSE + N_IMPORTANCE) * 16
+                                                                                        + 48 + (N_COARSE + N_IMPORTANCE) * 4)),
                          "flop_per_launch": flop_launch, "ms_per_launch": ms_launch,
                          "ms_coarse_launch": ms_mlp_c, "ms_fine_launch": ms_mlp_f},
             "roofline_composite": {"kernel": "composite_kernel<3> (fine pass)", "bound": "hbm",
