@@ -250,3 +250,30 @@ def test_error_codes(dev):
         ops.composite(torch.zeros(4, 96, 4, device=dev), torch.zeros(96, device=dev))    # not a multiple of 64
     assert ops.mlp_forward_points(torch.zeros(ops.packed_floats(), device=dev), torch.zeros(0, 3, device=dev),
                                   torch.zeros(0, 3, device=dev)).shape == (0, 4)        # empty input is fine
+
+
+def test_distillation_records(dev, tmp_path):
+    """gen_dist_data.py's per-view record (keys, shapes, file names) from the HIP renderer, two 'ranks'."""
+    from nerf_amd import distill
+    from nerf_amd.camera import focal_from_angle, test_set_poses
+    from nerf_amd.config import default_cfg
+    from nerf_amd.network import Network
+    from nerf_amd.renderer import Renderer
+    from nerf_amd.weights import make_state_dict
+    net = Network()
+    net.load_state_dict(make_state_dict(0, 30.0, 2.0))
+    r = Renderer(net.to(dev), default_cfg(perturb=0))
+    poses = test_set_poses(200)[:3]
+    p0 = distill.generate(r, poses, 16, 16, focal_from_angle(16), str(tmp_path), dev, rank=0, world=2)
+    torch.manual_seed(5)                       # the importance-sampling uniforms are drawn per render call
+    p1 = distill.generate(r, poses, 16, 16, focal_from_angle(16), str(tmp_path), dev, rank=1, world=2)
+    assert [p.split("/")[-1] for p in p0] == ["dist_0000.pt", "dist_0002.pt"] and [p.split("/")[-1] for p in p1] == ["dist_0001.pt"]
+    rec = torch.load(p1[0], weights_only=True)
+    assert set(rec) == {"xyz", "viewdirs", "teacher_rgb", "teacher_alpha"}
+    assert rec["xyz"].shape == (256, 3) and rec["teacher_rgb"].shape == (256, 3) and rec["teacher_alpha"].shape == (256, 1)
+    assert not rec["teacher_rgb"].is_cuda and torch.isfinite(rec["teacher_rgb"]).all()
+    # same numbers as rendering that view directly
+    o, d = rec["xyz"].to(dev), rec["viewdirs"].to(dev)
+    torch.manual_seed(5)
+    out = r.render({"xyz": o[None], "viewdirs": d[None], "gt_rgb": o[None]}, is_training=False)
+    assert torch.equal(out["fine_rgb_map"].cpu(), rec["teacher_rgb"])
