@@ -87,6 +87,18 @@ int nrf_mlp_forward_rays(const float* packed, const float* rays_o, const float* 
 int nrf_mlp_forward_points(const float* packed, const float* pts, const float* dirs, int64_t n_points,
                            float* raw, nrf_stream_t stream);
 
+/* ---- bf16 MLP variant (BASELINE configs[4]) ------------------------------------------------ */
+
+/* Same network and reference path as nrf_pack_weights / nrf_mlp_forward_rays (network.py:49-74, 171-195,
+ * volume_renderer.py:227-231, 393-423), evaluated on v_mfma_f32_32x32x16_bf16: matrix weights and every layer
+ * input (encodings, relu'd activations, feature vector) rounded to bf16 (nearest even), fp32 accumulation, fp32
+ * biases, fp32 alpha / rgb heads.  n_samples must be a multiple of 64.  Stated tolerance against the fp32
+ * reference: see tests/test_gpu_bf16.py. */
+int64_t nrf_packed_bf16_bytes(void);
+int nrf_pack_weights_bf16(const float* const* w, const float* const* b, void* packed_bf16, nrf_stream_t stream);
+int nrf_mlp_forward_rays_bf16(const void* packed_bf16, const float* rays_o, const float* rays_d, const float* z,
+                              int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream);
+
 /* ---- alpha compositing: volume_renderer.py:222-224, 236-265 / 291-334 --------------- */
 
 /* sigma = relu(raw[...,3]); rgb = sigmoid(raw[...,:3]); delta = diff(z), last = 1e10;

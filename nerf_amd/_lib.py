@@ -22,6 +22,7 @@ SYMBOLS = (
     "nrf_kilo_packed_floats", "nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward_workspace_bytes",
     "nrf_kilo_forward", "nrf_kilo_march_workspace_bytes", "nrf_kilo_march_count", "nrf_kilo_march_write",
     "nrf_kilo_composite", "nrf_occ_bake_workspace_bytes", "nrf_occ_bake",
+    "nrf_packed_bf16_bytes", "nrf_pack_weights_bf16", "nrf_mlp_forward_rays_bf16",
 )
 
 P = C.c_void_p
@@ -86,6 +87,12 @@ def lib() -> C.CDLL:
     L.nrf_clip_adam.argtypes = [P, P, P, P, I64, F, F, F, F, F, F, INT, P]
     L.nrf_mse_grad.restype = INT
     L.nrf_clip_adam.restype = INT
+    L.nrf_packed_bf16_bytes.restype = I64
+    L.nrf_packed_bf16_bytes.argtypes = []
+    L.nrf_pack_weights_bf16.restype = INT
+    L.nrf_pack_weights_bf16.argtypes = [P, P, P, P]
+    L.nrf_mlp_forward_rays_bf16.restype = INT
+    L.nrf_mlp_forward_rays_bf16.argtypes = [P, P, P, P, I64, I64, INT, P, P]
     L.nrf_occ_bake_workspace_bytes.restype = I64
     L.nrf_occ_bake_workspace_bytes.argtypes = [I64]
     L.nrf_occ_bake.restype = INT

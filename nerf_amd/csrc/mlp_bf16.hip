@@ -1,0 +1,396 @@
+// bf16 variant of the fused point construction + positional encoding + 8x256 NeRF MLP
+// (BASELINE configs[4]: "bf16 MLP"; same reference path as mlp_fp32.hip: volume_renderer.py:227-231, 393-423,
+// network.py:49-74, 171-195, encoding/freq.py:31-32).
+//
+// Numerics (the stated bf16 rule, restated in oracle/nerf_oracle.py:network_forward(bf16=True)):
+//   * matrix weights and every layer INPUT (encodings, relu'd hidden activations, the feature vector) are rounded
+//     to bf16 (round-to-nearest-even); products accumulate in fp32 on v_mfma_f32_32x32x16_bf16; biases are fp32
+//     accumulator initialisers; point construction, sin/cos, the alpha / rgb heads (fp32 weights, VALU) are fp32.
+//
+// Shape (what differs from the fp32 kernel): one MFMA now covers 16 k for 32 cycles (16x the fp32 rate), so the
+// weight stream, not the matrix pipe, is the thing to feed: a wavefront owns 64 points (two 32-point accumulator
+// sets that share every weight operand: one ds_read_b128 per 2 MFMAs), the LDS ring moves 32-KiB chunks (one
+// barrier per 2048 matrix cycles) and its LDS-DMA refills are spread one piece every 4 steps.  Activations live in
+// registers as bf16 B fragments (v_cvt_pk_bf16_f32 of accumulator registers 8s..8s+7 = the fragment of k-step s,
+// cdna_hip_programming.md section 3): a finished 32-row output block is activated and packed while the next
+// block accumulates, so only two fp32 accumulator blocks per point set are ever live and the layer's input and
+// output (128 registers each) ping-pong between two register arrays.
+#include "mlp_chain.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kBChunkSteps = 32;                   // 1-KiB steps per ring chunk
+constexpr int kBChunkBytes = kBChunkSteps * 1024;  // 32 KiB
+constexpr int kBRing = 4;
+constexpr int kBStepsL0 = 8 * 2 * 2;               // 8 out blocks x 2 PE k-blocks x 2 k16-steps
+constexpr int kBStepsHidden = 8 * 8 * 2;           // 128
+constexpr int kBStepsSkip = 8 * 10 * 2;            // 160: per output block 2 PE k-blocks then 8 hidden
+constexpr int kBStepsViewsPad = 96;                // views: 4 x 9 x 2 = 72 used steps of 3 chunks
+constexpr int kBStreamSteps = kBStepsL0 + 7 * kBStepsHidden + kBStepsSkip + kBStepsViewsPad;  // 1184
+constexpr int kBChunks = kBStreamSteps / kBChunkSteps;                                         // 37
+static_assert(kBStreamSteps % kBChunkSteps == 0, "stream must be whole chunks");
+// stream offsets (steps): pts0, pts1..4, pts5 (skip), pts6, pts7, feature, views
+constexpr int kBLayerStep[10] = {0, 32, 160, 288, 416, 544, 704, 832, 960, 1088};
+constexpr int64_t kBSmallFloatOff = int64_t(kBStreamSteps) * 256;  // small block (fp32) behind the stream
+constexpr int kBLdsConstOff = kBRing * kBChunkBytes;               // 128 KiB
+constexpr int kBLdsBytes = kBLdsConstOff + kSmallFloats * 4;       // + 12.1 KiB
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round to nearest even
+    return __builtin_bit_cast(unsigned, v);
+}
+// registers 8s..8s+7 of a 32x32 accumulator (or encoding) tile -> the bf16 B fragment of k16-step s
+__device__ __forceinline__ void pack_tile(const f32x16& v, u32x4 out[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[s][i] = pack_bf16(v[8 * s + 2 * i], v[8 * s + 2 * i + 1]);
+}
+
+// ---- weight packing ------------------------------------------------------------------------
+struct BPackLayer {
+    const float* W;
+    unsigned short* dst;
+    int ldw, nob;
+    int pre_kb, hid_kb, post_kb;
+    int pre_L, post_L;
+    int pre_col0, hid_col0, post_col0;
+};
+
+__device__ __forceinline__ unsigned short bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+__global__ void bpack_layer_kernel(BPackLayer p) {
+    const int nkb = p.pre_kb + p.hid_kb + p.post_kb;
+    const int total = p.nob * nkb * 2 * 512;  // bf16 elements
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
+    const int s2 = step & 1, kbpos = (step >> 1) % nkb, ob = (step >> 1) / nkb;
+    const int h = lane >> 5, t = 8 * s2 + jj;
+    const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
+    float v = 0.f;
+    if (kbpos < p.pre_kb) {
+        const int c = pe_col(kbpos * 16 + t, h, p.pre_L);
+        if (c >= 0) v = p.W[row + p.pre_col0 + c];
+    } else if (kbpos < p.pre_kb + p.hid_kb) {
+        v = p.W[row + p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
+    } else {
+        const int c = pe_col((kbpos - p.pre_kb - p.hid_kb) * 16 + t, h, p.post_L);
+        if (c >= 0) v = p.W[row + p.post_col0 + c];
+    }
+    p.dst[idx] = bf16_bits(v);
+}
+
+// ---- LDS ring of the bf16 stream --------------------------------------------------------------
+struct BRing {
+    const char* gnext;   // per lane: this lane's 16 B of piece 8w of the next chunk to prefetch
+    const char* gbegin;
+    const char* gend;
+    unsigned lds_base;   // LDS byte address of smem + wave * 8 KiB (this wave fills pieces 8w..8w+7)
+    char* smem;
+    int pf_slot, rd_slot;
+    const u32x4* rd;     // this lane's 16 B of step 0 of the chunk being read
+    u32x4 w;             // weights of the next step to be multiplied (already read from LDS)
+};
+
+__device__ __forceinline__ void br_prefetch_piece(const BRing& st, int j) {
+    glds16(st.gnext + j * 1024, st.lds_base + unsigned(st.pf_slot) * kBChunkBytes + j * 1024);
+}
+__device__ __forceinline__ void br_prefetch_advance(BRing& st) {
+    const char* nx = st.gnext + kBChunkBytes;
+    st.gnext = nx == st.gend ? st.gbegin : nx;
+    asm volatile("" : "+v"(st.gnext));  // keep it a run-time value (see ws_prefetch_advance)
+    st.pf_slot = st.pf_slot + 1 == kBRing ? 0 : st.pf_slot + 1;
+}
+// Next chunk readable: it was issued two chunk-times ago; the two batches of 8 pieces issued since may stay in
+// flight.  The barrier also says every wave is done reading the current chunk (its slot is refilled next).
+__device__ __forceinline__ void br_acquire(BRing& st, int lane) {
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = st.rd_slot + 1 == kBRing ? 0 : st.rd_slot + 1;
+    st.rd = reinterpret_cast<const u32x4*>(st.smem + st.rd_slot * kBChunkBytes) + lane;
+}
+// Chunks 0..2 are fetched up front; while chunk c is consumed the wave issues its 8 pieces of chunk c+3 into the
+// slot chunk c-1 just left.
+__device__ __forceinline__ void br_start(BRing& st, const char* stream_base, char* smem, int wave, int lane) {
+    st.gbegin = stream_base + wave * 8192 + lane * 16;
+    st.gend = st.gbegin + size_t(kBChunks) * kBChunkBytes;
+    st.gnext = st.gbegin;
+    st.smem = smem;
+    st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * 8192u);
+    st.pf_slot = 0;
+#pragma unroll
+    for (int i = 0; i < kBRing - 1; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) br_prefetch_piece(st, jj);
+        br_prefetch_advance(st);
+    }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = 0;
+    st.rd = reinterpret_cast<const u32x4*>(smem) + lane;
+    st.w = st.rd[0];
+}
+
+#define NRF_MFMA_BF16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// activation of a finished accumulator block: max(bits, lim) as integers is relu for lim = 0 (negative floats are
+// negative ints) and the identity for lim = INT_MIN, so "relu or not" is a run-time scalar, not another code body
+__device__ __forceinline__ void act_pack(const f32x16& y, int lim, u32x4 out[2]) {
+    f32x16 v;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int bits = __float_as_int(y[t]);
+        v[t] = __int_as_float(bits > lim ? bits : lim);
+    }
+    pack_tile(v, out);
+}
+
+struct EpiPack {  // hidden layers: activate + pack block ob of both sets into the next layer's input
+    u32x4 (*Xout)[8][2];
+    int lim;
+    __device__ __forceinline__ void operator()(int ob, const f32x16& ya, const f32x16& yb) {
+        act_pack(ya, lim, Xout[0][ob]);
+        act_pack(yb, lim, Xout[1][ob]);
+    }
+};
+struct EpiRgb {  // views layer: relu + the rgb head's partial dot products (fp32 weights on the VALU)
+    const float* rw;  // cst + rgb weights + h * 16
+    float acc[2][3];
+    __device__ __forceinline__ void operator()(int ob, const f32x16& ya, const f32x16& yb) {
+        const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + ob * 32);
+        const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + ob * 32);
+        const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + ob * 32);
+        const f32x16 ha = relu16(ya), hb = relu16(yb);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            acc[0][0] = fmaf(w0[t], ha[t], acc[0][0]), acc[0][1] = fmaf(w1[t], ha[t], acc[0][1]), acc[0][2] = fmaf(w2[t], ha[t], acc[0][2]);
+            acc[1][0] = fmaf(w0[t], hb[t], acc[1][0]), acc[1][1] = fmaf(w1[t], hb[t], acc[1][1]), acc[1][2] = fmaf(w2[t], hb[t], acc[1][2]);
+        }
+    }
+};
+
+// One GEMM layer for this wave's two 32-point sets: block ob of the output = bias + sum_k W . [pre, Xin, post].
+// The epilogue of block ob-1 (activation + pack, or the rgb head) runs early in block ob's k loop, when the MFMAs
+// that produced it have long drained.  NS steps are consumed; the layer occupies NSPAD steps of the stream.
+template <int NOB, int NPRE, int NHID, int NPOST, int NSPAD, class Epi>
+__device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_h, const u32x4 (*pre)[2][2],
+                                         const u32x4 (*Xin)[8][2], const u32x4 (*post)[2], Epi& epi) {
+    constexpr int NKB = NPRE + NHID + NPOST;
+    constexpr int NS = NOB * NKB * 2;
+    static_assert(NSPAD % kBChunkSteps == 0 && NSPAD >= NS && NSPAD - NS < kBChunkSteps, "layer padding");
+    f32x16 acc[2][2];  // [ob & 1][set]
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        {
+            const f32x16 b = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+            acc[ob & 1][0] = b, acc[ob & 1][1] = b;
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (ob > 0 && kb == 1) epi(ob - 1, acc[(ob - 1) & 1][0], acc[(ob - 1) & 1][1]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int s = (ob * NKB + kb) * 2 + s2;
+                const int cs = s % kBChunkSteps;               // position inside the ring chunk
+                const bool last = s == NS - 1;
+                const bool hand = cs == kBChunkSteps - 1 || last;
+                const u32x4 w = st.w;
+                if (last && NS % kBChunkSteps != 0) {          // padded tail: this chunk-time's remaining refill pieces
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int jj = (NS % kBChunkSteps + 2) / 4; jj < 8; ++jj) br_prefetch_piece(st, jj);
+                    br_prefetch_advance(st);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (hand) br_acquire(st, lane);
+                st.w = st.rd[(hand ? 0 : cs + 1) * 64];
+                const u32x4 xa = kb < NPRE ? pre[0][kb][s2] : (kb < NPRE + NHID ? Xin[0][kb - NPRE][s2] : post[0][s2]);
+                const u32x4 xb = kb < NPRE ? pre[1][kb][s2] : (kb < NPRE + NHID ? Xin[1][kb - NPRE][s2] : post[1][s2]);
+                acc[ob & 1][0] = NRF_MFMA_BF16(w, xa, acc[ob & 1][0]);
+                if (cs % 4 == 1 && !(last && NS % kBChunkSteps != 0)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    br_prefetch_piece(st, cs / 4);
+                    if (cs / 4 == 7) br_prefetch_advance(st);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[ob & 1][1] = NRF_MFMA_BF16(w, xb, acc[ob & 1][1]);
+            }
+        }
+    }
+    epi(NOB - 1, acc[(NOB - 1) & 1][0], acc[(NOB - 1) & 1][1]);
+}
+
+__device__ __forceinline__ float bf_lo(unsigned r) { return __uint_as_float(r << 16); }
+__device__ __forceinline__ float bf_hi(unsigned r) { return __uint_as_float(r & 0xffff0000u); }
+
+// Persistent, one 4-wave workgroup per CU, one wave per SIMD; a wave's tile = 64 consecutive samples of one ray.
+__global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict__ packed, const float* __restrict__ rays_o,
+                                                          const float* __restrict__ rays_d, const float* __restrict__ zbuf,
+                                                          int64_t z_stride, int tiles_per_ray, int64_t n_tiles,
+                                                          int64_t n_groups, float4* __restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    {
+        const float4* src = reinterpret_cast<const float4*>(packed + kBSmallFloatOff * 4);
+        float4* dst = reinterpret_cast<float4*>(smem + kBLdsConstOff);
+        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* cst = reinterpret_cast<const float*>(smem + kBLdsConstOff);
+    const float* bias_h = cst + h * 16;
+
+    BRing st;
+    br_start(st, packed, smem, wave, lane);
+
+    for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+        int64_t tile = tg * 4 + wave;
+        const bool valid = tile < n_tiles;
+        if (!valid) tile = n_tiles - 1;
+        const int64_t ray = tile / tiles_per_ray;
+        const int s0 = int(tile - ray * tiles_per_ray) * 64;
+        const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+        float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+        const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // volume_renderer.py:230 (torch's 3-element norm)
+        dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
+        u32x4 pe[2][2][2], dpe[2][2];
+#pragma unroll
+        for (int set = 0; set < 2; ++set) {
+            const float zz = zbuf[ray * z_stride + s0 + 32 * set + j];
+            const float px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
+            const float py = __fadd_rn(oy, __fmul_rn(zz, dy));
+            const float pz = __fadd_rn(oz, __fmul_rn(zz, dz));
+            pack_tile(encode_block<10, 0>(px, py, pz, h), pe[set][0]);
+            pack_tile(encode_block<10, 1>(px, py, pz, h), pe[set][1]);
+        }
+        pack_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[0]);  // both sets are samples of the same ray
+        dpe[1][0] = dpe[0][0], dpe[1][1] = dpe[0][1];
+
+        u32x4 XA[2][8][2], XB[2][8][2];
+        {
+            EpiPack e{XA, 0};
+            bf_layer<8, 2, 0, 0, kBStepsL0>(st, lane, bias_h, pe, nullptr, nullptr, e);                    // pts_linears.0
+        }
+        // pts1..7 + feature as 4 pairs (XA -> XB -> XA); pair 2 starts with the skip layer, the last layer of pair 3
+        // is feature_linear (no activation)
+        for (int p = 0; p < 4; ++p) {
+            const float* b0 = bias_h + (2 * p + 1) * 256;
+            EpiPack e0{XB, 0};
+            if (p == 2)
+                bf_layer<8, 2, 8, 0, kBStepsSkip>(st, lane, b0, pe, XA, nullptr, e0);                      // cat([pe, h]) (network.py:58)
+            else
+                bf_layer<8, 0, 8, 0, kBStepsHidden>(st, lane, b0, nullptr, XA, nullptr, e0);
+            EpiPack e1{XA, p == 3 ? int(0x80000000u) : 0};
+            bf_layer<8, 0, 8, 0, kBStepsHidden>(st, lane, b0 + 256, nullptr, XB, nullptr, e1);
+        }
+        // XB = bf16(relu(h7)): alpha_linear, fp32 weights on the VALU
+        float sigma[2] = {0.f, 0.f};
+        {
+            const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
+#pragma unroll
+                for (int set = 0; set < 2; ++set)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned r = XB[set][kb][s2][i];
+                            sigma[set] = fmaf(w[8 * s2 + 2 * i], bf_lo(r), sigma[set]);
+                            sigma[set] = fmaf(w[8 * s2 + 2 * i + 1], bf_hi(r), sigma[set]);
+                        }
+            }
+        }
+        // views_linears.0 on cat([feature (XA, no activation), dir PE]) -> 128, relu, rgb_linear
+        EpiRgb er{cst + (kOffRgbW - kOffBias) + h * 16, {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}};
+        bf_layer<4, 0, 8, 1, kBStepsViewsPad>(st, lane, bias_h + 9 * 256, nullptr, XA, dpe, er);
+        const float* rb = cst + (kOffRgbB - kOffBias);
+        const float ab = cst[kOffAlphaB - kOffBias];
+#pragma unroll
+        for (int set = 0; set < 2; ++set) {
+            float r = er.acc[set][0], g = er.acc[set][1], b = er.acc[set][2];
+            r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32);
+            const float sg = sigma[set] + __shfl_xor(sigma[set], 32);
+            if (h == 0 && valid) raw[tile * 64 + 32 * set + j] = make_float4(r + rb[0], g + rb[1], b + rb[2], sg + ab);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+}
+
+}  // namespace
+
+NRF_EXPORT int64_t nrf_packed_bf16_bytes(void) { return kBSmallFloatOff * 4 + int64_t(kSmallFloats) * 4; }
+
+NRF_EXPORT int nrf_pack_weights_bf16(const float* const* w, const float* const* b, void* packed, nrf_stream_t stream_) {
+    if (!w || !b || !packed) return NRF_ERR_NULL;
+    for (int i = 0; i < NRF_NUM_LAYERS; ++i)
+        if (!w[i] || !b[i]) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned short* base = static_cast<unsigned short*>(packed);
+    nrf_launch_begin();
+    (void)hipMemsetAsync(packed, 0, size_t(kBStreamSteps) * 1024, stream);  // views-layer padding steps stay zero
+    auto launch = [&](BPackLayer p, int step0) {
+        p.dst = base + int64_t(step0) * 512;
+        const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
+        bpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+    };
+    launch(BPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0}, kBLayerStep[0]);
+    for (int l = 1; l <= 7; ++l) {
+        if (l == 5)  // network.py:58 cat([input_pts, h]): PE columns 0..62 then hidden 63..318, per output block
+            launch(BPackLayer{w[5], nullptr, 319, 8, 2, 8, 0, 10, 0, 0, 63, 0}, kBLayerStep[5]);
+        else
+            launch(BPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kBLayerStep[l]);
+    }
+    launch(BPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kBLayerStep[8]);     // feature_linear
+    launch(BPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256}, kBLayerStep[9]);   // views_linears.0
+    PackSmall s;
+    for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
+    s.bias[8] = b[8];
+    s.bias[9] = b[10];
+    s.alpha_w = w[9];
+    s.alpha_b = b[9];
+    s.rgb_w = w[11];
+    s.rgb_b = b[11];
+    s.packed = static_cast<float*>(packed);
+    s.small_shift = kBSmallFloatOff - kOffBias;
+    pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_mlp_forward_rays_bf16(const void* packed_bf16, const float* rays_o, const float* rays_d, const float* z,
+                                         int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 64 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (!packed_bf16 || !rays_o || !rays_d || !z || !raw) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed_bf16) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
+    const int tiles_per_ray = n_samples / 64;
+    const int64_t n_tiles = n_rays * tiles_per_ray;
+    const int64_t groups = (n_tiles + 3) / 4;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    static bool attr_set[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kBLdsBytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const unsigned grid = unsigned(groups < cus ? groups : cus);
+    nrf_launch_begin();
+    mlp_bf16_kernel<<<dim3(grid), 256, kBLdsBytes, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const char*>(packed_bf16), rays_o, rays_d, z, z_stride, tiles_per_ray, n_tiles, groups,
+        reinterpret_cast<float4*>(raw));
+    return nrf_launch_status();
+}

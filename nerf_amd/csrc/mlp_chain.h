@@ -182,6 +182,41 @@ __device__ __forceinline__ void mfma_layer(WeightStream& st, int lane, const flo
     }
 }
 
+// biases + head weights block ([layer][ob][h][16] accumulator order), shared by the fp32 and bf16 packers
+struct PackSmall {
+    const float* bias[10];  // pts0..7, feature, views
+    const float* alpha_w;
+    const float* alpha_b;
+    const float* rgb_w;
+    const float* rgb_b;
+    float* packed;
+    int64_t small_shift;  // floats; 0 for the fp32 layout
+};
+
+__attribute__((unused)) static __global__ void pack_small_kernel(PackSmall p, int64_t stream_pad_at, int pad_floats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float* dst = p.packed;
+    if (idx < pad_floats) dst[stream_pad_at + idx] = 0.f;  // stream tail pad (fp32 layout only)
+    if (idx >= kSmallFloats) return;
+    const int64_t o = kOffBias + idx;
+    dst += p.small_shift;  // where this layout keeps the small block relative to the fp32 layout's kOffBias
+    if (o < kOffAlphaW) {  // [layer][ob][h][r]
+        const int layer = idx >> 8, r = idx & 15, h = (idx >> 4) & 1, ob = (idx >> 5) & 7;
+        dst[o] = p.bias[layer][ob * 32 + acc_row(r, h)];
+    } else if (o < kOffAlphaB) {  // alpha weights [kb][h][t]
+        const int i = int(o - kOffAlphaW), t = i & 15, h = (i >> 4) & 1, kb = i >> 5;
+        dst[o] = p.alpha_w[32 * kb + acc_row(t, h)];
+    } else if (o < kOffRgbW) {
+        dst[o] = o == kOffAlphaB ? p.alpha_b[0] : 0.f;
+    } else if (o < kOffRgbB) {  // rgb weights [c][kb][h][t]
+        const int i = int(o - kOffRgbW), t = i & 15, h = (i >> 4) & 1, kb = (i >> 5) & 3, c = i >> 7;
+        dst[o] = p.rgb_w[c * 128 + 32 * kb + acc_row(t, h)];
+    } else {
+        const int i = int(o - kOffRgbB);
+        dst[o] = i < 3 ? p.rgb_b[i] : 0.f;
+    }
+}
+
 // Start the ring: fill all kRing slots from the stream [gbegin, gend), then take chunk 0.
 __device__ __forceinline__ void ws_start(WeightStream& st, const char* stream_base, int n_chunks, char* smem,
                                          int wave, int lane) {

@@ -59,38 +59,6 @@ __global__ void pack_layer_kernel(PackLayer p) {
     p.dst[idx] = v;
 }
 
-struct PackSmall {
-    const float* bias[10];  // pts0..7, feature, views
-    const float* alpha_w;
-    const float* alpha_b;
-    const float* rgb_w;
-    const float* rgb_b;
-    float* packed;
-};
-
-__global__ void pack_small_kernel(PackSmall p) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    float* dst = p.packed;
-    if (idx < kPrefetch * kStepFloats) dst[int64_t(kStreamSteps) * kStepFloats + idx] = 0.f;  // stream tail pad
-    if (idx >= kSmallFloats) return;
-    const int64_t o = kOffBias + idx;
-    if (o < kOffAlphaW) {  // [layer][ob][h][r]
-        const int layer = idx >> 8, r = idx & 15, h = (idx >> 4) & 1, ob = (idx >> 5) & 7;
-        dst[o] = p.bias[layer][ob * 32 + acc_row(r, h)];
-    } else if (o < kOffAlphaB) {  // alpha weights [kb][h][t]
-        const int i = int(o - kOffAlphaW), t = i & 15, h = (i >> 4) & 1, kb = i >> 5;
-        dst[o] = p.alpha_w[32 * kb + acc_row(t, h)];
-    } else if (o < kOffRgbW) {
-        dst[o] = o == kOffAlphaB ? p.alpha_b[0] : 0.f;
-    } else if (o < kOffRgbB) {  // rgb weights [c][kb][h][t]
-        const int i = int(o - kOffRgbW), t = i & 15, h = (i >> 4) & 1, kb = (i >> 5) & 3, c = i >> 7;
-        dst[o] = p.rgb_w[c * 128 + 32 * kb + acc_row(t, h)];
-    } else {
-        const int i = int(o - kOffRgbB);
-        dst[o] = i < 3 ? p.rgb_b[i] : 0.f;
-    }
-}
-
 NRF_EXPORT int64_t nrf_packed_floats(void) { return kPackedFloats; }
 
 NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, float* packed, nrf_stream_t stream_) {
@@ -129,7 +97,8 @@ NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, fl
     s.rgb_w = w[11];
     s.rgb_b = b[11];
     s.packed = packed;
-    pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s);
+    s.small_shift = 0;
+    pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, int64_t(kStreamSteps) * kStepFloats, kPrefetch * kStepFloats);
     return nrf_launch_status();
 }
 

@@ -104,26 +104,38 @@ def pos_enc(x: torch.Tensor, L: int) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 # the 8x256 MLP -- src/models/nerf/network.py:49-74, 171-195
 # --------------------------------------------------------------------------------------
-def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Tensor) -> torch.Tensor:
-    """``NeRF.forward`` (network.py:49-74): raw ``[r, g, b, sigma]`` per point, no activation."""
-    def lin(name, h):
-        return F.linear(h, sd[f"{prefix}.{name}.weight"], sd[f"{prefix}.{name}.bias"])
+def _q_bf16(t: torch.Tensor) -> torch.Tensor:
+    """Round to bf16 (nearest even) and back: what an MFMA operand of the bf16 kernel holds."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Tensor, bf16: bool = False) -> torch.Tensor:
+    """``NeRF.forward`` (network.py:49-74): raw ``[r, g, b, sigma]`` per point, no activation.
+
+    ``bf16=True`` restates the numerics of nrf_mlp_forward_rays_bf16 (mlp_bf16.hip): the weights and the input of
+    every MFMA layer (pts_linears, feature_linear, views_linears) are rounded to bf16, accumulation and biases are
+    fp32; alpha_linear reads the bf16-rounded relu(h7) with fp32 weights, rgb_linear is all fp32."""
+    q = _q_bf16 if bf16 else (lambda t: t)
+
+    def lin(name, h, mfma=True):
+        w = sd[f"{prefix}.{name}.weight"]
+        return F.linear(q(h), q(w), sd[f"{prefix}.{name}.bias"]) if mfma else F.linear(h, w, sd[f"{prefix}.{name}.bias"])
 
     h = emb_pts
     for i in range(8):
         h = torch.relu(lin(f"pts_linears.{i}", h))
         if i == 4:                                   # network.py:57-58: [input_pts, h]
             h = torch.cat([emb_pts, h], -1)
-    alpha = lin("alpha_linear", h)                   # :61, raw
+    alpha = lin("alpha_linear", q(h), mfma=False)    # :61, raw
     feature = lin("feature_linear", h)               # :62, no activation
     h = torch.cat([feature, emb_dirs], -1)           # :63
     h = torch.relu(lin("views_linears.0", h))        # :65-67
-    rgb = lin("rgb_linear", h)                       # :69
+    rgb = lin("rgb_linear", h, mfma=False)           # :69
     return torch.cat([rgb, alpha], -1)               # :70
 
 
 def network_forward(sd: dict, pts: torch.Tensor, dirs: torch.Tensor, model: str = "",
-                    chunk: int = 65536, dtype=None) -> torch.Tensor:
+                    chunk: int = 65536, dtype=None, bf16: bool = False) -> torch.Tensor:
     """``Network.forward`` (network.py:171-195). ``pts`` (R,S,3) with ``dirs`` (R,3), or
     ``pts`` (P,3) with ``dirs`` (P,3).  Returns (..., 4).
 
@@ -140,7 +152,7 @@ def network_forward(sd: dict, pts: torch.Tensor, dirs: torch.Tensor, model: str 
     for i in range(0, flat.shape[0], chunk):
         e = pos_enc(flat[i:i + chunk], 10)
         ed = pos_enc(dflat[i:i + chunk], 4)
-        outs.append(mlp_forward(sd, prefix, e, ed))
+        outs.append(mlp_forward(sd, prefix, e, ed, bf16))
     out = torch.cat(outs, 0)
     return out.reshape(list(pts.shape[:-1]) + [4])
 
