@@ -35,6 +35,7 @@ N_COARSE, N_IMPORTANCE = 64, 128
 MACS_PER_POINT = 593_408
 FLOP_PER_POINT = 2 * MACS_PER_POINT
 FP32_MFMA_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0
 
 
@@ -47,6 +48,9 @@ def parse():
                     help="render: BASELINE configs[1] (default, the headline metric); train: configs[2], "
                          "4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce; kilo: configs[3], KiloNeRF "
                          "800x800 frame with the sphere occupancy grid")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="render mode only: fp32 = BASELINE configs[1] (the headline metric); bf16 = the bf16 MLP of "
+                         "configs[4], reported under its own metric name")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -265,7 +269,9 @@ def main():
     net.to(dev)
     if args.mode == "train":
         return train_bench(args, net, dev, rank, world, dist)
-    renderer = Renderer(net, default_cfg(perturb=0))
+    renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=args.dtype)
+    bf16 = args.dtype == "bf16"
+    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
     R = H * W
@@ -313,7 +319,7 @@ def main():
         achieved = flop_launch / (ms_launch * 1e-3) / 1e12
         cmp_bytes = R * ((N_COARSE + N_IMPORTANCE) * 20 + 20)
         line = {
-            "metric": "rays/sec (full 800x800 frame, 64 coarse + 128 fine samples/ray)",
+            "metric": "rays/sec (full 800x800 frame, 64 coarse + 128 fine samples/ray)" + (", bf16 MLP" if bf16 else ""),
             "value": world * R * args.steps / elapsed,
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -322,14 +328,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if bf16 else "f32",
             "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
-            "config": {"workload": "BASELINE configs[1]: full 800x800 lego test-view render, NeRF coarse+fine, fp32, "
+            "config": {"workload": ("BASELINE configs[4] per-view form: full 800x800 test-view render, NeRF coarse+fine, bf16 MLP "
+                                    "(bf16 weights + activations, fp32 accumulate), " if bf16 else
+                                    "BASELINE configs[1]: full 800x800 lego test-view render, NeRF coarse+fine, fp32, ") +
                                    "one view per rank per step", "rays_per_frame": R, "n_coarse": N_COARSE,
                        "n_importance": N_IMPORTANCE, "sharding": f"views round-robin over {world} rank(s)"},
-            "roofline": {"kernel": "mlp_fwd_kernel<true> (fused points + PE + 8x256 MLP, fp32 MFMA)",
-                         "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": recorded_traffic(),
+            "roofline": {"kernel": "mlp_bf16_kernel (fused points + PE + 8x256 MLP, bf16 MFMA)" if bf16 else
+                                   "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
+                         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None if bf16 else recorded_traffic(),
                          "traffic_note": "HBM bytes per launch (mean of coarse + fine) from profiles/r01_mlp_traffic_pmc.json; "
                                          "algorithmic bytes per launch %.4g" % (0.5 * R * ((N_COARSE + N_COARSE + N_IMPORTANCE) * 16
                                                                                         + 48 + (N_COARSE + N_IMPORTANCE) * 4)),

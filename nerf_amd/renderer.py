@@ -75,7 +75,10 @@ class _RenderTrainFn(torch.autograd.Function):
 
 
 class Renderer(nn.Module):
-    def __init__(self, net, cfg=None):
+    """``mlp_dtype``: "fp32" (default, the reference's precision) or "bf16" (BASELINE configs[4]: the MLP on the bf16
+    matrix cores, inference only; ``cfg.task_arg.mlp_dtype`` is read when the argument is None)."""
+
+    def __init__(self, net, cfg=None, mlp_dtype: str | None = None):
         super().__init__()
         if cfg is None:
             try:  # inside the reference tree: its global config (volume_renderer.py:8)
@@ -93,6 +96,11 @@ class Renderer(nn.Module):
         self.near = ta.near
         self.far = ta.far
         self.chunk_size = ta.chunk_size if getattr(ta, "chunk_size", 0) > 0 else 1024
+        self.mlp_dtype = mlp_dtype or getattr(ta, "mlp_dtype", "fp32")
+        if self.mlp_dtype not in ("fp32", "bf16"):
+            raise NrfError(f"mlp_dtype {self.mlp_dtype!r}: expected 'fp32' or 'bf16'")
+        if self.mlp_dtype == "bf16" and (self.N_samples % 64 or (self.N_samples + self.N_importance) % 64):
+            raise NrfError("the bf16 MLP kernel needs sample counts that are multiples of 64")
         if self.raw_noise_std and self.raw_noise_std > 0:
             # the reference calls an undefined bare add_noise() here (:241, :310) and would crash
             raise NrfError("raw_noise_std > 0 is not supported (the reference's noise branch is broken)")
@@ -109,7 +117,7 @@ class Renderer(nn.Module):
         self._workspace = None
 
     # ---- weights ---------------------------------------------------------------------
-    def _packed_model(self, name: str, device) -> torch.Tensor:
+    def _packed_model(self, name: str, device, bf16: bool = False) -> torch.Tensor:
         model = getattr(self.net, name)
         params = []
         for ln in ops.LAYER_NAMES:
@@ -118,14 +126,15 @@ class Renderer(nn.Module):
                 mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
             params += [mod.weight, mod.bias]
         key = tuple((p.data_ptr(), p._version) for p in params) + (str(device),)
-        hit = self._packed.get(name)
+        slot = name + (":bf16" if bf16 else "")
+        hit = self._packed.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
         buf = hit[1] if hit is not None and hit[1].device == torch.device(device) else None
         ws = [p if p.device == torch.device(device) else p.to(device) for p in params[0::2]]
         bs = [p if p.device == torch.device(device) else p.to(device) for p in params[1::2]]
-        buf = ops.pack_weights(ws, bs, out=buf)
-        self._packed[name] = (key, buf)
+        buf = (ops.pack_weights_bf16 if bf16 else ops.pack_weights)(ws, bs, out=buf)
+        self._packed[slot] = (key, buf)
         return buf
 
     def _model_params(self, name: str):
@@ -194,7 +203,11 @@ class Renderer(nn.Module):
         u2 = torch.rand(R, ni, device=dev)
         u_fine = torch.rand((R, ni), dtype=torch.float32, device=dev) if perturbed else None
         if needs_grad:
+            if self.mlp_dtype != "fp32":
+                raise NrfError("training runs the fp32 kernels: construct the Renderer with mlp_dtype='fp32'")
             return self.render_rays_train(rays_o, rays_d, u, u2, u_coarse, u_fine)
+        if self.mlp_dtype == "bf16":   # nrf_render is the fp32 pipeline; the bf16 MLP goes stage by stage
+            return self.render_rays_staged(rays_o, rays_d, u, u2, u_coarse, u_fine)
         return self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
 
     def render_rays_staged(self, rays_o, rays_d, u, u2, u_coarse=None, u_fine=None, events=None):
@@ -205,8 +218,10 @@ class Renderer(nn.Module):
         nc = self.N_samples
         if self._bins is None or self._bins.device != dev:
             self._bins = torch.from_numpy(near_far_table(self.near, self.far, nc)).to(dev)
-        pc = self._packed_model("model", dev)
-        pf = self._packed_model("model_fine", dev)
+        bf16 = self.mlp_dtype == "bf16"
+        mlp = ops.mlp_forward_rays_bf16 if bf16 else ops.mlp_forward_rays
+        pc = self._packed_model("model", dev, bf16)
+        pf = self._packed_model("model_fine", dev, bf16)
         white = self.white_bkgd > 0
 
         def stage(name, fn, *a, **k):
@@ -220,11 +235,11 @@ class Renderer(nn.Module):
             return out
 
         zc = self._bins if u_coarse is None else stage("perturb", ops.perturb_samples, self._bins, u_coarse)
-        raw = stage("mlp_coarse", ops.mlp_forward_rays, pc, rays_o, rays_d, zc)
+        raw = stage("mlp_coarse", mlp, pc, rays_o, rays_d, zc)
         c_rgb, c_depth, w_c, _ = stage("composite_coarse", ops.composite, raw, zc, white, True)
         z_f = stage("sample_fine", ops.sample_fine, w_c, self._bins, zc, u, u2, u_fine)
         del raw
-        raw = stage("mlp_fine", ops.mlp_forward_rays, pf, rays_o, rays_d, z_f)
+        raw = stage("mlp_fine", mlp, pf, rays_o, rays_d, z_f)
         f_rgb, f_depth, _, f_acc = stage("composite_fine", ops.composite, raw, z_f, white, False)
         return {
             "coarse_rgb_map": c_rgb, "coarse_depth_map": c_depth,
