@@ -98,6 +98,9 @@ struct BRing {
 };
 
 __device__ __forceinline__ void br_prefetch_piece(const BRing& st, int j) {
+#ifdef BF_ABL_NODMA  // timing-only ablation builds (tools/debug/bf16_ablate.py): results are wrong
+    return;
+#endif
     glds16(st.gnext + j * 1024, st.lds_base + unsigned(st.pf_slot) * kBChunkBytes + j * 1024);
 }
 __device__ __forceinline__ void br_prefetch_advance(BRing& st) {
@@ -109,8 +112,10 @@ __device__ __forceinline__ void br_prefetch_advance(BRing& st) {
 // Next chunk readable: it was issued two chunk-times ago; the two batches of 8 pieces issued since may stay in
 // flight.  The barrier also says every wave is done reading the current chunk (its slot is refilled next).
 __device__ __forceinline__ void br_acquire(BRing& st, int lane) {
+#ifndef BF_ABL_NOBARRIER
     asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#endif
     st.rd_slot = st.rd_slot + 1 == kBRing ? 0 : st.rd_slot + 1;
     st.rd = reinterpret_cast<const u32x4*>(st.smem + st.rd_slot * kBChunkBytes) + lane;
 }
@@ -139,8 +144,10 @@ __device__ __forceinline__ void br_start(BRing& st, const char* stream_base, cha
 #define NRF_MFMA_BF16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-// activation of a finished accumulator block: max(bits, lim) as integers is relu for lim = 0 (negative floats are
-// negative ints) and the identity for lim = INT_MIN, so "relu or not" is a run-time scalar, not another code body
+// Activation of a finished accumulator block: max(bits, lim) as integers is relu for lim = 0 (negative floats are
+// negative ints) and the identity for lim = INT_MIN, so "relu or not" is a run-time scalar, not another code body.
+// (relu on the PACKED pairs with one v_pk_max_i16 would halve it, but that form produced wrong activations inside
+// this kernel although it is correct in isolation -- not understood, so not used.)
 __device__ __forceinline__ void act_pack(const f32x16& y, int lim, u32x4 out[2]) {
     f32x16 v;
 #pragma unroll
@@ -150,8 +157,9 @@ __device__ __forceinline__ void act_pack(const f32x16& y, int lim, u32x4 out[2])
     }
     pack_tile(v, out);
 }
+constexpr int kActRelu = 0, kActNone = int(0x80000000u);
 
-struct EpiPack {  // hidden layers: activate + pack block ob of both sets into the next layer's input
+struct EpiPack {  // hidden layers: pack + activate block ob of both sets into the next layer's input
     u32x4 (*Xout)[8][2];
     int lim;
     __device__ __forceinline__ void operator()(int ob, const f32x16& ya, const f32x16& yb) {
@@ -187,10 +195,7 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
     f32x16 acc[2][2];  // [ob & 1][set]
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
-        {
-            const f32x16 b = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
-            acc[ob & 1][0] = b, acc[ob & 1][1] = b;
-        }
+        const f32x16 bias = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);  // srcC of the block's first MFMAs
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             if (ob > 0 && kb == 1) epi(ob - 1, acc[(ob - 1) & 1][0], acc[(ob - 1) & 1][1]);
@@ -209,17 +214,20 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (hand) br_acquire(st, lane);
+#ifndef BF_ABL_NOLDS
                 st.w = st.rd[(hand ? 0 : cs + 1) * 64];
+#endif
                 const u32x4 xa = kb < NPRE ? pre[0][kb][s2] : (kb < NPRE + NHID ? Xin[0][kb - NPRE][s2] : post[0][s2]);
                 const u32x4 xb = kb < NPRE ? pre[1][kb][s2] : (kb < NPRE + NHID ? Xin[1][kb - NPRE][s2] : post[1][s2]);
-                acc[ob & 1][0] = NRF_MFMA_BF16(w, xa, acc[ob & 1][0]);
+                const bool first = kb == 0 && s2 == 0;
+                acc[ob & 1][0] = NRF_MFMA_BF16(w, xa, first ? bias : acc[ob & 1][0]);
                 if (cs % 4 == 1 && !(last && NS % kBChunkSteps != 0)) {
                     __builtin_amdgcn_sched_barrier(0);
                     br_prefetch_piece(st, cs / 4);
                     if (cs / 4 == 7) br_prefetch_advance(st);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                acc[ob & 1][1] = NRF_MFMA_BF16(w, xb, acc[ob & 1][1]);
+                acc[ob & 1][1] = NRF_MFMA_BF16(w, xb, first ? bias : acc[ob & 1][1]);
             }
         }
     }
@@ -275,19 +283,19 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
 
         u32x4 XA[2][8][2], XB[2][8][2];
         {
-            EpiPack e{XA, 0};
+            EpiPack e{XA, kActRelu};
             bf_layer<8, 2, 0, 0, kBStepsL0>(st, lane, bias_h, pe, nullptr, nullptr, e);                    // pts_linears.0
         }
         // pts1..7 + feature as 4 pairs (XA -> XB -> XA); pair 2 starts with the skip layer, the last layer of pair 3
         // is feature_linear (no activation)
         for (int p = 0; p < 4; ++p) {
             const float* b0 = bias_h + (2 * p + 1) * 256;
-            EpiPack e0{XB, 0};
+            EpiPack e0{XB, kActRelu};
             if (p == 2)
                 bf_layer<8, 2, 8, 0, kBStepsSkip>(st, lane, b0, pe, XA, nullptr, e0);                      // cat([pe, h]) (network.py:58)
             else
                 bf_layer<8, 0, 8, 0, kBStepsHidden>(st, lane, b0, nullptr, XA, nullptr, e0);
-            EpiPack e1{XA, p == 3 ? int(0x80000000u) : 0};
+            EpiPack e1{XA, p == 3 ? kActNone : kActRelu};
             bf_layer<8, 0, 8, 0, kBStepsHidden>(st, lane, b0 + 256, nullptr, XB, nullptr, e1);
         }
         // XB = bf16(relu(h7)): alpha_linear, fp32 weights on the VALU

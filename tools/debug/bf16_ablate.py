@@ -1,0 +1,41 @@
+"""Times nrf_mlp_forward_rays_bf16 from an arbitrary build of the library (ablation builds: results are wrong,
+only the time means something).  usage: bf16_ablate.py <lib.so> [<lib.so> ...]"""
+import ctypes as C
+import sys
+import time
+
+import torch
+
+P = C.c_void_p
+dev = torch.device("cuda:0")
+R, S = 65536, 192
+g = torch.Generator().manual_seed(0)
+o = (torch.tensor([0.0, 0.0, 4.0]) + 0.1 * torch.randn(R, 3, generator=g)).to(dev)
+d = torch.randn(R, 3, generator=g)
+d[:, 2] = -d[:, 2].abs() - 1
+d = d.to(dev)
+z = torch.sort(2 + 4 * torch.rand(R, S, generator=g), -1).values.to(dev)
+raw = torch.empty(R, S, 4, device=dev)
+shapes = [(256, 63)] + [(256, 256)] * 4 + [(256, 319)] + [(256, 256)] * 3 + [(1, 256), (128, 283), (3, 128)]
+ws = [torch.randn(s, device=dev) * 0.05 for s in shapes]
+bs = [torch.zeros(s[0], device=dev) for s in shapes]
+for path in sys.argv[1:]:
+    L = C.CDLL(path)
+    L.nrf_packed_bf16_bytes.restype = C.c_int64
+    packed = torch.zeros(L.nrf_packed_bf16_bytes(), dtype=torch.uint8, device=dev)
+    wp = (P * 12)(*[w.data_ptr() for w in ws])
+    bp = (P * 12)(*[b.data_ptr() for b in bs])
+    assert L.nrf_pack_weights_bf16(wp, bp, P(packed.data_ptr()), None) == 0
+
+    def run():
+        st = L.nrf_mlp_forward_rays_bf16(P(packed.data_ptr()), P(o.data_ptr()), P(d.data_ptr()), P(z.data_ptr()),
+                                         C.c_int64(S), C.c_int64(R), C.c_int(S), P(raw.data_ptr()), None)
+        assert st == 0, st
+    run()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 3
+    print(f"{path.split('/')[-1]:40s} {dt * 1e3:8.2f} ms  {R * S * 1186816 / dt / 1e12:7.1f} TFLOP/s", flush=True)

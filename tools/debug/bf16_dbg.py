@@ -1,5 +1,8 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
+from nerf_amd import _lib
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = sys.argv[1]
 from nerf_amd import ops
 from nerf_amd.weights import make_state_dict, make_state_dict_arrays
 from nerf_amd.renderer import near_far_table
@@ -13,7 +16,7 @@ g = torch.Generator().manual_seed(0)
 R = 300
 o = torch.tensor([0.0, 0.0, 4.0]) + 0.1 * torch.randn(R, 3, generator=g)
 d = torch.randn(R, 3, generator=g); d[:, 2] = -d[:, 2].abs() - 1
-for S in (64, 192):
+for S in (64,):
     z = torch.sort(2 + 4 * torch.rand(R, S, generator=g), -1).values
     raw = ops.mlp_forward_rays_bf16(pb, o.to(dev), d.to(dev), z.to(dev)).cpu()
     raw32 = ops.mlp_forward_rays(pf, o.to(dev), d.to(dev), z.to(dev)).cpu()
@@ -25,12 +28,3 @@ for S in (64, 192):
           "| gpu-bf16 vs fp32 ref: rgb", float((raw[..., :3] - ref[..., :3]).abs().max()), "sigma", float((raw[..., 3] - ref[..., 3]).abs().max()),
           "| oracle-bf16 vs fp32 ref: rgb", float((ref_b[..., :3] - ref[..., :3]).abs().max()), "sigma", float((ref_b[..., 3] - ref[..., 3]).abs().max()),
           "| fp32 gpu vs ref", float((raw32 - ref).abs().max()), flush=True)
-# timing on 65536 rays x 192
-R = 65536
-o = (torch.tensor([0.0, 0.0, 4.0]) + 0.1 * torch.randn(R, 3, generator=g)).to(dev)
-d = torch.randn(R, 3, generator=g); d[:, 2] = -d[:, 2].abs() - 1; d = d.to(dev)
-z = torch.sort(2 + 4 * torch.rand(R, 192, generator=g), -1).values.to(dev)
-for name, fn, p in (("bf16", ops.mlp_forward_rays_bf16, pb), ("fp32", ops.mlp_forward_rays, pf)):
-    fn(p, o, d, z); torch.cuda.synchronize()
-    t = time.perf_counter(); fn(p, o, d, z); torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print(name, f"{dt*1e3:.2f} ms", f"{R*192*1186816/dt/1e12:.1f} TFLOP/s", flush=True)
