@@ -26,6 +26,7 @@ namespace {
 constexpr int kBChunkSteps = 32;                   // 1-KiB steps per ring chunk
 constexpr int kBChunkBytes = kBChunkSteps * 1024;  // 32 KiB
 constexpr int kBRing = 4;
+constexpr int kLook = 3;                           // LDS -> register look-ahead of the weight operands, in steps
 constexpr int kBStepsL0 = 8 * 2 * 2;               // 8 out blocks x 2 PE k-blocks x 2 k16-steps
 constexpr int kBStepsHidden = 8 * 8 * 2;           // 128
 constexpr int kBStepsSkip = 8 * 10 * 2;            // 160: per output block 2 PE k-blocks then 8 hidden
@@ -94,7 +95,7 @@ struct BRing {
     char* smem;
     int pf_slot, rd_slot;
     const u32x4* rd;     // this lane's 16 B of step 0 of the chunk being read
-    u32x4 w;             // weights of the next step to be multiplied (already read from LDS)
+    u32x4 wq[4];         // weights of steps s .. s+2 (slot = step & 3), read kLook steps ahead of their MFMAs
 };
 
 __device__ __forceinline__ void br_prefetch_piece(const BRing& st, int j) {
@@ -138,7 +139,8 @@ __device__ __forceinline__ void br_start(BRing& st, const char* stream_base, cha
     __builtin_amdgcn_s_barrier();
     st.rd_slot = 0;
     st.rd = reinterpret_cast<const u32x4*>(smem) + lane;
-    st.w = st.rd[0];
+#pragma unroll
+    for (int i = 0; i < kLook; ++i) st.wq[i] = st.rd[i * 64];
 }
 
 #define NRF_MFMA_BF16(a, b, c) \
@@ -192,6 +194,8 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
     constexpr int NKB = NPRE + NHID + NPOST;
     constexpr int NS = NOB * NKB * 2;
     static_assert(NSPAD % kBChunkSteps == 0 && NSPAD >= NS && NSPAD - NS < kBChunkSteps, "layer padding");
+    static_assert(NS % 4 == 0 && (NS % kBChunkSteps == 0 || (NS % kBChunkSteps) % 4 == 0) && (NS % kBChunkSteps == 0 || NS % kBChunkSteps > kLook),
+                  "register ring phase / tail length");
     f32x16 acc[2][2];  // [ob & 1][set]
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
@@ -201,32 +205,34 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
             if (ob > 0 && kb == 1) epi(ob - 1, acc[(ob - 1) & 1][0], acc[(ob - 1) & 1][1]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                // Step s uses the weights in register slot s & 3 and issues the LDS read of step s + kLook (one
+                // ds_read_b128 in flight across ~3 steps = 6 MFMAs, so its latency never surfaces).  The hand-over to
+                // the next ring chunk comes kLook steps before the chunk's end, right after the read of its last step
+                // was issued: by then every wave has ISSUED all its reads of the chunk (and br_acquire drains them
+                // before the barrier), so the chunk's slot may be refilled from the next chunk's step 0 on.
                 const int s = (ob * NKB + kb) * 2 + s2;
-                const int cs = s % kBChunkSteps;               // position inside the ring chunk
-                const bool last = s == NS - 1;
-                const bool hand = cs == kBChunkSteps - 1 || last;
-                const u32x4 w = st.w;
-                if (last && NS % kBChunkSteps != 0) {          // padded tail: this chunk-time's remaining refill pieces
+                const int cs = s % kBChunkSteps;                                        // position inside the ring chunk
+                const int cend = (s - cs + kBChunkSteps - 1) < NS - 1 ? (s - cs + kBChunkSteps - 1) : NS - 1;  // chunk's last step
+                const bool tail = cend - (s - cs) + 1 < kBChunkSteps;                   // padded (short) last chunk of the layer
+                const u32x4 w = st.wq[s & 3];
+                const int r = s + kLook;
+                if (r <= cend) st.wq[r & 3] = st.rd[(cs + kLook) * 64];
+                if (cs % 4 == 0) {                                                      // this chunk-time's refill pieces
                     __builtin_amdgcn_sched_barrier(0);
+                    br_prefetch_piece(st, cs / 4);
+                    if (s == cend - kLook && tail) {
 #pragma unroll
-                    for (int jj = (NS % kBChunkSteps + 2) / 4; jj < 8; ++jj) br_prefetch_piece(st, jj);
-                    br_prefetch_advance(st);
+                        for (int jj = cs / 4 + 1; jj < 8; ++jj) br_prefetch_piece(st, jj);
+                    }
+                    if (cs / 4 == 7 || (s == cend - kLook && tail)) br_prefetch_advance(st);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (hand) br_acquire(st, lane);
-#ifndef BF_ABL_NOLDS
-                st.w = st.rd[(hand ? 0 : cs + 1) * 64];
-#endif
+                if (s == cend - kLook) br_acquire(st, lane);
+                if (r > cend) st.wq[r & 3] = st.rd[(r - cend - 1) * 64];
                 const u32x4 xa = kb < NPRE ? pre[0][kb][s2] : (kb < NPRE + NHID ? Xin[0][kb - NPRE][s2] : post[0][s2]);
                 const u32x4 xb = kb < NPRE ? pre[1][kb][s2] : (kb < NPRE + NHID ? Xin[1][kb - NPRE][s2] : post[1][s2]);
                 const bool first = kb == 0 && s2 == 0;
                 acc[ob & 1][0] = NRF_MFMA_BF16(w, xa, first ? bias : acc[ob & 1][0]);
-                if (cs % 4 == 1 && !(last && NS % kBChunkSteps != 0)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    br_prefetch_piece(st, cs / 4);
-                    if (cs / 4 == 7) br_prefetch_advance(st);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 acc[ob & 1][1] = NRF_MFMA_BF16(w, xb, first ? bias : acc[ob & 1][1]);
             }
         }
@@ -317,6 +323,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
                         }
             }
         }
+        // Pin the alpha head HERE: LLVM otherwise sinks it to its use behind the views layer and keeps XB alive across
+        // it in scratch -- and every scratch reload's vmcnt(0) also drains the LDS-DMA ring (measured: 42 % of the
+        // kernel's wave time parked in s_waitcnt).
+        asm volatile("" : "+v"(sigma[0]), "+v"(sigma[1]));
         // views_linears.0 on cat([feature (XA, no activation), dir PE]) -> 128, relu, rgb_linear
         EpiRgb er{cst + (kOffRgbW - kOffBias) + h * 16, {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}};
         bf_layer<4, 0, 8, 1, kBStepsViewsPad>(st, lane, bias_h + 9 * 256, nullptr, XA, dpe, er);
