@@ -44,10 +44,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", default="render", choices=["render", "train", "kilo"],
+    ap.add_argument("--mode", default="render", choices=["render", "train", "kilo", "kilo_train"],
                     help="render: BASELINE configs[1] (default, the headline metric); train: configs[2], "
                          "4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce; kilo: configs[3], KiloNeRF "
-                         "800x800 frame with the sphere occupancy grid")
+                         "800x800 frame with the sphere occupancy grid; kilo_train: KiloNeRF distillation step (SURVEY 8f rank 3)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="render mode only: fp32 = BASELINE configs[1] (the headline metric); bf16 = the bf16 MLP of "
                          "configs[4], reported under its own metric name")
@@ -241,6 +241,80 @@ def kilo_bench(args, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def kilo_train_bench(args, dev, rank, world, dist):
+    """KiloNeRF distillation step (configs/kilonerf/lego.yaml: batch_size 4 x N_rays 1024 rays per rank):
+    march + tiny MLPs + packed compositing, mse(rgb) + mse(alpha) + l2_reg colour regulariser, backward, gradient
+    all-reduce (mean), clip 40, Adam over all 25.4 M parameters.  Weak scaling: every rank has its own batch."""
+    from nerf_amd import ops
+    from nerf_amd.camera import test_set_poses, focal_from_angle
+    from nerf_amd.kilo_train import KiloTrainStep
+    from nerf_amd.kilonerf import KiloNetwork, KiloRenderer, default_kilo_cfg
+    from nerf_amd.weights import make_kilo_state_dict_arrays
+    net = KiloNetwork()
+    sd = make_kilo_state_dict_arrays(0, 4096, 10.0, 0.5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net.to(dev)
+    c = (torch.arange(256, device=dev, dtype=torch.float32) + 0.5) / 256 * 2 - 1
+    occ = ((c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2).sqrt() < 0.75).to(torch.uint8)
+    r = KiloRenderer(net, default_kilo_cfg(), occ)
+    ts = KiloTrainStep(r, dev, lr=5e-4, clip_value=40.0, l2_reg=1e-6)
+    poses = test_set_poses(200)
+    focal = focal_from_angle(W)
+    R = args.train_rays
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(977 + rank)
+    samples = []
+
+    def step(k):
+        pix = torch.randint(0, H * W, (R,), device=dev, generator=gen)
+        rays_o, rays_d = ops.raygen(poses[(k * world + rank) % len(poses)], H, W, focal, dev, pixel_index=pix)
+        t_rgb = torch.rand((R, 3), device=dev, generator=gen)
+        t_alpha = torch.rand((R, 1), device=dev, generator=gen)
+        ts.step(rays_o, rays_d, t_rgb, t_alpha, stage="distillation")
+        samples.append(ts.num_samples)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(ts.loss)
+    assert loss == loss
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        n = float(np.mean(samples[args.warmup:]))
+        adam_bytes = 28.0 * ts.flat.numel()                  # SURVEY 8d: 16 B read + 12 B write per parameter
+        print(json.dumps({
+            "metric": "training rays/sec (KiloNeRF distillation step: fwd+bwd+Adam)",
+            "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (random pixels of orbit views, random targets, random-init cells, sphere occupancy)",
+            "config": {"workload": "KiloNeRF distillation step (SURVEY 8f rank 3), %d-ray batch per rank, 4096 cells, "
+                                   "dense Adam over 25.4 M parameters, data-parallel RCCL all-reduce" % R,
+                       "rays_per_rank": R, "samples_per_step": n},
+            "roofline": {"kernel": "clip_adam_kernel over the flat parameter buffer (dominant: the step is optimiser-bound)",
+                         "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                         "note": "algorithmic bytes of the Adam pass = %.0f MB per step; see DESIGN.md section 7 for the "
+                                 "per-kernel times (rocprofv3)" % (adam_bytes / 1e6)},
+            "final_loss": loss}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -264,6 +338,8 @@ def main():
 
     if args.mode == "kilo":
         return kilo_bench(args, dev, rank, world, dist)
+    if args.mode == "kilo_train":
+        return kilo_train_bench(args, dev, rank, world, dist)
     net = Network()
     net.load_state_dict(make_state_dict(0, 30.0, 2.0))   # random init, density rescaled so rays terminate
     net.to(dev)

@@ -215,6 +215,39 @@ int nrf_occ_bake(const float* packed_teacher, const float* aabb_host, const int*
                  int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
                  nrf_stream_t stream);
 
+/* ---- KiloNeRF training: what loss.backward() does in src/train/trainers/trainer.py:68-75 for the KiloNeRF
+ * wrapper (src/train/trainers/kilonerf.py:34-63) ---- */
+
+/* A operands of the transposed chain (pts_linears 1, feature_linear, view_linears feature columns). */
+int64_t nrf_kilo_packed_bwd_floats(int num_cells);
+int nrf_kilo_pack_weights_transposed(const float* const* tensors_host, int num_cells, float* packed_t,
+                                     nrf_stream_t stream);
+
+/* Backward of nrf_kilo_composite (this library's own rule; the termination mask is a constant):
+ * grad_rgb (n_rays, 3), grad_depth (n_rays,) or NULL, grad_acc (n_rays,) or NULL -> grad_raw (n, 4), every
+ * sample written.  Autograd through volumn_renderer.py:89-116 under the rule above. */
+int nrf_kilo_composite_backward(const float* raw, const float* t_start, const float* t_end, const int32_t* offsets,
+                                const int32_t* counts, int64_t n_rays, float ert_eps, int white_bkgd,
+                                const float* grad_rgb, const float* grad_depth, const float* grad_acc, float* grad_raw,
+                                nrf_stream_t stream);
+
+/* Backward of nrf_kilo_forward w.r.t. the 12 parameter tensors (autograd through BatchedKiloNeRF.forward,
+ * kilonerf/network.py:123-167): `forward_workspace` is the workspace nrf_kilo_forward filled for these same
+ * points (it holds their order by cell) and must be untouched since.  grads_host: HOST array of 12 DEVICE
+ * pointers shaped like the parameter tensors (nrf_kilo_pack_weights order); every element is overwritten
+ * (zeros for cells without points); partial sums per job of a few tiles, added in job order: no atomics,
+ * reproducible for a given forward workspace. */
+int64_t nrf_kilo_backward_workspace_bytes(int64_t n_points, int num_cells);
+int nrf_kilo_backward(const float* packed, const float* packed_t, int num_cells, const float* pts, const float* dirs,
+                      const int32_t* dir_index, int64_t n_points, const float* grad_raw, const void* forward_workspace,
+                      int64_t forward_workspace_bytes, float* const* grads_host, void* workspace,
+                      int64_t workspace_bytes, nrf_stream_t stream);
+
+/* *loss_accum += coeff * sum(p^2), grad_accum[i] += 2 coeff p[i] (either may be NULL): the colour regulariser
+ * l2_reg * Network.get_color_reg_loss() (kilonerf/network.py:357-384, trainers/kilonerf.py:52-55), one call per
+ * tensor (view_linears_{weights,biases}, rgb_linear_{weights,biases}). */
+int nrf_l2_reg(const float* params, int64_t n, float coeff, float* grad_accum, float* loss_accum, nrf_stream_t stream);
+
 /* ---- whole forward path: volume_renderer.py:143-153 (render_coarse + render_fine) --- */
 
 typedef struct nrf_render_args {

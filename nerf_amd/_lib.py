@@ -23,6 +23,8 @@ SYMBOLS = (
     "nrf_kilo_forward", "nrf_kilo_march_workspace_bytes", "nrf_kilo_march_count", "nrf_kilo_march_write",
     "nrf_kilo_composite", "nrf_occ_bake_workspace_bytes", "nrf_occ_bake",
     "nrf_packed_bf16_bytes", "nrf_pack_weights_bf16", "nrf_mlp_forward_rays_bf16",
+    "nrf_kilo_packed_bwd_floats", "nrf_kilo_pack_weights_transposed", "nrf_kilo_composite_backward",
+    "nrf_kilo_backward_workspace_bytes", "nrf_kilo_backward", "nrf_l2_reg",
 )
 
 P = C.c_void_p
@@ -109,6 +111,16 @@ def lib() -> C.CDLL:
     L.nrf_kilo_march_count.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, I64, P]
     L.nrf_kilo_march_write.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, P, P]
     L.nrf_kilo_composite.argtypes = [P, P, P, P, P, I64, F, INT, P, P, P, P]
+    L.nrf_kilo_packed_bwd_floats.restype = I64
+    L.nrf_kilo_packed_bwd_floats.argtypes = [INT]
+    L.nrf_kilo_pack_weights_transposed.argtypes = [P, INT, P, P]
+    L.nrf_kilo_composite_backward.argtypes = [P, P, P, P, P, I64, F, INT, P, P, P, P, P]
+    L.nrf_kilo_backward_workspace_bytes.restype = I64
+    L.nrf_kilo_backward_workspace_bytes.argtypes = [I64, INT]
+    L.nrf_kilo_backward.argtypes = [P, P, INT, P, P, P, I64, P, P, I64, P, P, I64, P]
+    L.nrf_l2_reg.argtypes = [P, I64, F, P, P, P]
+    for name in ("nrf_kilo_pack_weights_transposed", "nrf_kilo_composite_backward", "nrf_kilo_backward", "nrf_l2_reg"):
+        getattr(L, name).restype = INT
     for name in ("nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward", "nrf_kilo_march_count",
                  "nrf_kilo_march_write", "nrf_kilo_composite"):
         getattr(L, name).restype = INT

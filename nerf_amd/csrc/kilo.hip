@@ -17,22 +17,9 @@
 //   * packed compositing is the same wave scan as composite.hip over a ragged segment.
 // nerfacc is absent and unpinned: the sampling / termination / packed-rendering rules below
 // are this repo's own specification, checked against oracle/kilo_oracle.py.
-#include "mlp_chain.h"
+#include "kilo_common.h"
 
 namespace {
-
-constexpr int kKiloSteps = 24;                 // float4-per-lane pieces of one cell's weights
-constexpr int kKiloSmall = 288;                // biases + heads, padded
-constexpr int kKiloCellFloats = kKiloSteps * 256 + kKiloSmall;  // 6432
-constexpr int kKOffBias = 0;                   // [4 layers: pts0, pts1, feature, view][h][16]
-constexpr int kKOffSigW = 128;                 // [h][16]
-constexpr int kKOffRgbW = 160;                 // [c][h][16]
-constexpr int kKOffSigB = 256, kKOffRgbB = 257;
-constexpr int kJobTiles = 16;                  // tiles of one cell handled per weight load
-
-struct KiloSrc {
-    const float* t[12];  // KILO tensor order: w0 b0 w1 b1 wf bf ws bs wv bv wr br, each (cells, ...)
-};
 
 __global__ void kilo_pack_kernel(KiloSrc s, int num_cells, float* __restrict__ packed) {
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -76,10 +63,6 @@ __global__ void kilo_pack_kernel(KiloSrc s, int num_cells, float* __restrict__ p
     packed[gid] = v;
 }
 
-struct Grid {
-    float mn[3], mx[3];
-    int res[3];
-};
 
 // kilonerf/network.py:322-334, op for op in fp32: (p - min) / (max - min) * res, clamp(min=0),
 // min(res - 1), truncate.  Bit-exact (IEEE subtract / divide / multiply, no contraction).
@@ -175,25 +158,6 @@ __global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict
         base = __shfl(base, head_lane);
         if (in) perm[base + (lane - head_lane)] = int(i);
     }
-}
-
-// One 32x32 output block of a tiny layer: Y = init + sum_k W . x over NKB k-blocks of 32.  `gap(m)` is called
-// behind MFMA number BASE + i of the tile with work to run in that MFMA's shadow.
-// One 32x32 output block of a tiny layer: Y = init + sum_k W . x over NKB k-blocks of 32.
-template <int NKB>
-__device__ __forceinline__ f32x16 tiny_layer(const float4* w, f32x16 init, const f32x16* x) {
-    f32x16 y = init;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 a = w[kb * 4 + q];
-            y = NRF_MFMA(a.x, x[kb][4 * q + 0], y);
-            y = NRF_MFMA(a.y, x[kb][4 * q + 1], y);
-            y = NRF_MFMA(a.z, x[kb][4 * q + 2], y);
-            y = NRF_MFMA(a.w, x[kb][4 * q + 3], y);
-        }
-    return y;
 }
 
 // Persistent waves over jobs; job = up to kJobTiles 32-point tiles of one cell's sorted segment.
@@ -461,14 +425,6 @@ __global__ __launch_bounds__(256) void kilo_composite_kernel(const float4* __res
     }
 }
 
-Grid make_grid(const float* aabb, const int* res) {
-    Grid g;
-    for (int a = 0; a < 3; ++a) g.mn[a] = aabb[a], g.mx[a] = aabb[3 + a], g.res[a] = res[a];
-    return g;
-}
-
-inline int64_t a256(int64_t n) { return (n + 255) & ~int64_t(255); }
-
 }  // namespace
 
 NRF_EXPORT int64_t nrf_kilo_packed_floats(int num_cells) {
@@ -504,7 +460,7 @@ NRF_EXPORT int nrf_kilo_route(const float* pts, int64_t n, const float* aabb_hos
     return nrf_launch_status();
 }
 
-// workspace of nrf_kilo_forward: cell (n) | perm (n) | hist, seg_start, cursor, job_prefix (ncell + 1 each)
+// workspace layout: kilo_common.h, kilo_sort_ws
 NRF_EXPORT int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_cells) {
     if (n_points < 0 || num_cells <= 0) return NRF_ERR_SHAPE;
     return 2 * a256(n_points * 4) + 4 * a256((int64_t(num_cells) + 1) * 4);
@@ -522,14 +478,9 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
     if (workspace_bytes < nrf_kilo_forward_workspace_bytes(n_points, num_cells)) return NRF_ERR_WORKSPACE;
     if (!nrf_aligned16(packed) || !nrf_aligned16(raw) || !nrf_aligned16(workspace)) return NRF_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    char* wsb = static_cast<char*>(workspace);
-    int* cell = reinterpret_cast<int*>(wsb);
-    int* perm = reinterpret_cast<int*>(wsb + a256(n_points * 4));
-    const int64_t tab = a256((int64_t(num_cells) + 1) * 4);
-    int* hist = reinterpret_cast<int*>(wsb + 2 * a256(n_points * 4));
-    int* seg_start = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + tab);
-    int* cursor = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + 2 * tab);
-    int* job_prefix = reinterpret_cast<int*>(reinterpret_cast<char*>(hist) + 3 * tab);
+    const KiloSortWs ws = kilo_sort_ws(workspace, n_points, num_cells);
+    int *cell = ws.cell, *perm = ws.perm, *hist = ws.hist, *seg_start = ws.seg_start, *cursor = ws.cursor,
+        *job_prefix = ws.job_prefix;
     const Grid g = make_grid(aabb_host, res_host);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

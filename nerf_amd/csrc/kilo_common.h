@@ -1,0 +1,69 @@
+// Shared pieces of the KiloNeRF kernels (kilo.hip: forward / marching / compositing, kilo_bwd.hip: backward).
+#pragma once
+#include "mlp_chain.h"
+
+namespace {
+
+constexpr int kKiloSteps = 24;                 // float4-per-lane pieces of one cell's weights
+constexpr int kKiloSmall = 288;                // biases + heads, padded
+constexpr int kKiloCellFloats = kKiloSteps * 256 + kKiloSmall;  // 6432
+constexpr int kKOffBias = 0;                   // [4 layers: pts0, pts1, feature, view][h][16]
+constexpr int kKOffSigW = 128;                 // [h][16]
+constexpr int kKOffRgbW = 160;                 // [c][h][16]
+constexpr int kKOffSigB = 256, kKOffRgbB = 257;
+constexpr int kJobTiles = 16;                  // tiles of one cell handled per weight load
+
+struct KiloSrc {
+    const float* t[12];  // KILO tensor order: w0 b0 w1 b1 wf bf ws bs wv bv wr br, each (cells, ...)
+};
+
+struct Grid {
+    float mn[3], mx[3];
+    int res[3];
+};
+
+// One 32x32 output block of a tiny layer: Y = init + sum_k W . x over NKB k-blocks of 32.
+template <int NKB>
+__device__ __forceinline__ f32x16 tiny_layer(const float4* w, f32x16 init, const f32x16* x) {
+    f32x16 y = init;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = w[kb * 4 + q];
+            y = NRF_MFMA(a.x, x[kb][4 * q + 0], y);
+            y = NRF_MFMA(a.y, x[kb][4 * q + 1], y);
+            y = NRF_MFMA(a.z, x[kb][4 * q + 2], y);
+            y = NRF_MFMA(a.w, x[kb][4 * q + 3], y);
+        }
+    return y;
+}
+
+__attribute__((unused)) Grid make_grid(const float* aabb, const int* res) {
+    Grid g;
+    for (int a = 0; a < 3; ++a) g.mn[a] = aabb[a], g.mx[a] = aabb[3 + a], g.res[a] = res[a];
+    return g;
+}
+
+__attribute__((unused)) inline int64_t a256(int64_t n) { return (n + 255) & ~int64_t(255); }
+
+
+// workspace of nrf_kilo_forward: cell (n) | perm (n) | hist, seg_start, cursor, job_prefix (ncell + 1 each)
+struct KiloSortWs {
+    int *cell, *perm, *hist, *seg_start, *cursor, *job_prefix;
+};
+__attribute__((unused)) inline KiloSortWs kilo_sort_ws(void* workspace, int64_t n_points, int num_cells) {
+    char* wsb = static_cast<char*>(workspace);
+    const int64_t tab = a256((int64_t(num_cells) + 1) * 4);
+    KiloSortWs w;
+    w.cell = reinterpret_cast<int*>(wsb);
+    w.perm = reinterpret_cast<int*>(wsb + a256(n_points * 4));
+    char* t = wsb + 2 * a256(n_points * 4);
+    w.hist = reinterpret_cast<int*>(t);
+    w.seg_start = reinterpret_cast<int*>(t + tab);
+    w.cursor = reinterpret_cast<int*>(t + 2 * tab);
+    w.job_prefix = reinterpret_cast<int*>(t + 3 * tab);
+    return w;
+}
+
+}  // namespace

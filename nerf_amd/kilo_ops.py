@@ -51,8 +51,10 @@ def kilo_route(pts: torch.Tensor, aabb, res) -> torch.Tensor:
     return cell
 
 
-def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, workspace=None) -> torch.Tensor:
-    """raw (n, 4) = [r, g, b, sigma] per point; dirs (n, 3) or (m, 3) with int32 dir_index (n,)."""
+def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, workspace=None,
+                 return_workspace: bool = False):
+    """raw (n, 4) = [r, g, b, sigma] per point; dirs (n, 3) or (m, 3) with int32 dir_index (n,).
+    ``return_workspace``: also return the workspace (the points' order by cell), which kilo_backward needs."""
     pts, dirs = _f32(pts, "pts").reshape(-1, 3), _f32(dirs, "dirs").reshape(-1, 3)
     n = pts.shape[0]
     if dir_index is None:
@@ -70,7 +72,75 @@ def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, w
     with torch.cuda.device(pts.device):
         check(lib().nrf_kilo_forward(_ptr(packed), num_cells, pa, pr, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,
                                      _ptr(raw), _ptr(workspace), workspace.numel(), _stream(pts)), "nrf_kilo_forward")
-    return raw
+    return (raw, workspace) if return_workspace else raw
+
+
+def kilo_pack_weights_transposed(tensors, out: torch.Tensor | None = None) -> torch.Tensor:
+    """A operands of the backward data-gradient chain (nrf_kilo_pack_weights_transposed)."""
+    ts = [_f32(t.detach(), "kilo tensor") for t in tensors]
+    num_cells = ts[0].shape[0]
+    dev = ts[0].device
+    n = int(lib().nrf_kilo_packed_bwd_floats(num_cells))
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+    ptrs = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(dev):
+        check(lib().nrf_kilo_pack_weights_transposed(ptrs, num_cells, _ptr(out), _stream(out)),
+              "nrf_kilo_pack_weights_transposed")
+    return out
+
+
+def kilo_backward(packed, packed_t, num_cells: int, pts, dirs, dir_index, grad_raw, forward_workspace, grads=None,
+                  workspace=None):
+    """Gradients of the 12 parameter tensors (KILO_TENSORS order, reference shapes) for the batch the last
+    kilo_forward(..., return_workspace=True) evaluated.  Every element of every gradient is written."""
+    pts, dirs = _f32(pts, "pts").reshape(-1, 3), _f32(dirs, "dirs").reshape(-1, 3)
+    n = pts.shape[0]
+    grad_raw = _f32(grad_raw, "grad_raw").reshape(-1, 4)
+    if grad_raw.shape[0] != n:
+        raise NrfError(f"grad_raw has {grad_raw.shape[0]} rows for {n} points")
+    dev = packed.device
+    if grads is None:
+        grads = [torch.empty((num_cells,) + shape, dtype=torch.float32, device=dev) for _, shape, _ in KILO_TENSORS]
+    for gten, (name, shape, _) in zip(grads, KILO_TENSORS):
+        if tuple(gten.shape) != (num_cells,) + shape or gten.dtype != torch.float32 or not gten.is_contiguous():
+            raise NrfError(f"grad of {name}: expected a contiguous float32 tensor of shape {(num_cells,) + shape}")
+    ptrs = (C.c_void_p * 12)(*[t.data_ptr() for t in grads])
+    need = int(lib().nrf_kilo_backward_workspace_bytes(n, num_cells))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().nrf_kilo_backward(_ptr(packed), _ptr(packed_t), num_cells, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,
+                                      _ptr(grad_raw), _ptr(forward_workspace), forward_workspace.numel(), ptrs,
+                                      _ptr(workspace), workspace.numel(), _stream(packed)), "nrf_kilo_backward")
+    return grads
+
+
+def kilo_composite_backward(raw, t_start, t_end, offsets, counts, ert_eps: float, white_bkgd: bool, grad_rgb,
+                            grad_depth=None, grad_acc=None) -> torch.Tensor:
+    """d(loss)/d(raw) (n, 4) from the gradients of kilo_composite's outputs."""
+    R = offsets.shape[0]
+    dev = offsets.device
+    grad_raw = torch.empty((raw.shape[0], 4), dtype=torch.float32, device=dev)
+    if raw.shape[0] == 0:
+        return grad_raw
+    g_rgb = _f32(grad_rgb, "grad_rgb").reshape(R, 3)
+    g_depth = None if grad_depth is None else _f32(grad_depth, "grad_depth").reshape(R)
+    g_acc = None if grad_acc is None else _f32(grad_acc, "grad_acc").reshape(R)
+    with torch.cuda.device(dev):
+        check(lib().nrf_kilo_composite_backward(_ptr(_f32(raw, "raw")), _ptr(t_start), _ptr(t_end), _ptr(offsets),
+                                                _ptr(counts), R, float(ert_eps), int(bool(white_bkgd)), _ptr(g_rgb),
+                                                _ptr(g_depth), _ptr(g_acc), _ptr(grad_raw), _stream(offsets)),
+              "nrf_kilo_composite_backward")
+    return grad_raw
+
+
+def l2_reg(param: torch.Tensor, coeff: float, grad_accum: torch.Tensor | None, loss_accum: torch.Tensor | None):
+    """loss_accum += coeff * sum(param^2); grad_accum += 2 coeff param (nrf_l2_reg)."""
+    p = _f32(param.detach(), "param")
+    with torch.cuda.device(p.device):
+        check(lib().nrf_l2_reg(_ptr(p), p.numel(), float(coeff), _ptr(grad_accum), _ptr(loss_accum), _stream(p)),
+              "nrf_l2_reg")
 
 
 def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: float, step: float):

@@ -7,6 +7,11 @@ buffers ``aabb_min``, ``aabb_max``, ``grid_resolution``) and the ``forward(pts, 
 /root/reference/src/models/kilonerf/renderer/volumn_renderer.py:14-123: ``forward(batch, is_training)``
 returns ``rgb_map (B,R,3)``, ``depth_map (B,R,1)``, ``alpha_map (B,R,1)``.
 
+With ``is_training`` under autograd the outputs are connected to the network's 12 parameter tensors through one
+``torch.autograd.Function`` whose backward runs the HIP backward kernels (nrf_kilo_composite_backward,
+nrf_kilo_backward), so the reference's trainer / optimizer work unchanged (src/train/trainers/kilonerf.py:34-63);
+``nerf_amd/kilo_train.py`` is the fused form of that step.
+
 All arithmetic runs in libnerf_amd.so (nrf_kilo_*); there is no torch fallback.  Sampling, early
 termination and packed compositing follow this repository's own rule (the reference delegates them to
 nerfacc, which is absent and unpinned): see DESIGN.md section 7 and oracle/kilo_oracle.py.
@@ -119,6 +124,36 @@ def _ref_layer_params(model):
     return [sd[n + ".weight"] for n in LAYER_NAMES], [sd[n + ".bias"] for n in LAYER_NAMES]
 
 
+class _KiloRenderFn(torch.autograd.Function):
+    """march -> tiny MLPs -> packed compositing, differentiable w.r.t. the 12 parameter tensors.  Sample positions
+    and the termination mask are constants (the reference marches under no_grad too, volumn_renderer.py:78-86)."""
+
+    @staticmethod
+    def forward(ctx, renderer, o, d, *params):
+        net = renderer.net
+        aabb, res = net.grid()
+        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, renderer.occ_grid, aabb, renderer.near,
+                                                                    renderer.far, renderer.step)
+        renderer.last_num_samples = int(pts.shape[0])
+        packed = net.packed()
+        raw, ws = kilo_ops.kilo_forward(packed, net.num_models, aabb, res, pts, d, ray_idx, return_workspace=True)
+        rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, renderer.ert, renderer.white_bkgd)
+        ctx.renderer = renderer
+        ctx.params = params
+        ctx.saved = (packed, pts, d, ray_idx, ts, te, offsets, counts, raw, ws)
+        return rgb, depth, acc
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc):
+        r = ctx.renderer
+        packed, pts, d, ray_idx, ts, te, offsets, counts, raw, ws = ctx.saved
+        g_raw = kilo_ops.kilo_composite_backward(raw, ts, te, offsets, counts, r.ert, r.white_bkgd, g_rgb.contiguous(),
+                                                 g_depth.contiguous(), g_acc.contiguous())
+        packed_t = kilo_ops.kilo_pack_weights_transposed(ctx.params)
+        grads = kilo_ops.kilo_backward(packed, packed_t, r.net.num_models, pts, d, ray_idx, g_raw, ws)
+        return (None, None, None) + tuple(grads)
+
+
 class KiloRenderer(nn.Module):
     """``Renderer(net)`` for KiloNeRF.  ``occ_grid``: (rx,ry,rz) bool/uint8 tensor (the reference loads or bakes
     it in ``__init__``, volumn_renderer.py:36-44; here it is handed in or set later with ``set_occ_grid``)."""
@@ -164,24 +199,32 @@ class KiloRenderer(nn.Module):
     def load_occ_grid(self, path: str, device=None):
         self.set_occ_grid(torch.load(path, map_location=device or "cpu", weights_only=True))
 
-    @torch.no_grad()
     def forward(self, batch, is_training: bool = True):
         if self.occ_grid is None:
             raise RuntimeError("KiloRenderer: no occupancy grid (set_occ_grid)")
         rays_o, viewdirs = batch["xyz"], batch["viewdirs"]
         B, R, _ = rays_o.shape
-        o, d = rays_o.reshape(-1, 3), viewdirs.reshape(-1, 3)
+        o, d = rays_o.reshape(-1, 3).contiguous(), viewdirs.reshape(-1, 3).contiguous()
+        if self.occ_grid.device != o.device:
+            self.occ_grid = self.occ_grid.to(o.device)
+        params = self.net.model.tensors()
+        if is_training and torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            rgb, depth, acc = _KiloRenderFn.apply(self, o, d, *params)
+        else:
+            with torch.no_grad():
+                rgb, depth, acc = self._render(o, d)
+        return {"rgb_map": rgb.view(B, R, 3), "depth_map": depth.view(B, R, 1), "alpha_map": acc.view(B, R, 1)}
+
+    def _render(self, o, d):
         aabb, res = self.net.grid()
-        occ = self.occ_grid if self.occ_grid.device == o.device else self.occ_grid.to(o.device)
-        self.occ_grid = occ
+        occ = self.occ_grid
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, occ, aabb, self.near, self.far, self.step)
         self.last_num_samples = int(pts.shape[0])
         if pts.shape[0]:
             raw = kilo_ops.kilo_forward(self.net.packed(), self.net.num_models, aabb, res, pts, d, ray_idx)
         else:
             raw = torch.empty((0, 4), dtype=torch.float32, device=o.device)
-        rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.ert, self.white_bkgd)
-        return {"rgb_map": rgb.view(B, R, 3), "depth_map": depth.view(B, R, 1), "alpha_map": acc.view(B, R, 1)}
+        return kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.ert, self.white_bkgd)
 
     def render(self, batch, is_training: bool = True):
         return self.forward(batch, is_training)

@@ -7,7 +7,10 @@ Parity status, per function:
   * ``route``, ``network_forward``, ``color_reg_loss``: **pinned** -- checked against fixtures made
     by running the real reference (``tools/gen_golden_kilo.py`` -> ``tests/golden/kilo_*.npz``).
     They restate src/models/kilonerf/network.py (paths relative to /root/reference).
-  * ``march``, ``composite_packed``, ``render``: **parity unpinned**.  The reference delegates
+  * gradients of ``network_forward`` w.r.t. the parameter tensors (torch autograd on this restatement): **pinned**
+    by ``tests/golden/kilo_network_grad.npz`` (autograd through the real reference network).
+  * ``march``, ``composite_packed``, ``composite_packed_torch`` (its differentiable form), ``render``,
+    ``train_loss``'s rendering part: **parity unpinned**.  The reference delegates
     occupancy-grid sampling, early ray termination and packed rendering to the third-party
     ``nerfacc`` package (src/models/kilonerf/renderer/volumn_renderer.py:47-51, 78-86, 107-113), which is
     neither vendored in the reference nor installed here, and whose version the reference does
@@ -168,6 +171,44 @@ def composite_packed(raw: np.ndarray, t_start, t_end, offsets, counts, ert_eps: 
         rgb[r] = (w[:, None] * c).sum(0) + ((1.0 - acc[r]) if white_bkgd else 0.0)
         depth[r] = (w * 0.5 * (ts[sl] + te[sl])).sum() / max(acc[r], float(np.finfo(np.float32).eps))
     return (rgb, depth, acc, margin) if want_margin else (rgb, depth, acc)
+
+
+def composite_packed_torch(raw: torch.Tensor, t_start, t_end, offsets, counts, ert_eps: float, white_bkgd: bool):
+    """``composite_packed`` in differentiable torch float64 (autograd gives the yardstick gradients of the packed
+    compositing rule; the termination mask is a constant, as in the HIP backward)."""
+    raw = raw.double().reshape(-1, 4)
+    ts = torch.as_tensor(np.asarray(t_start, dtype=np.float64))
+    te = torch.as_tensor(np.asarray(t_end, dtype=np.float64))
+    rgbs, depths, accs = [], [], []
+    for r in range(len(offsets)):
+        b, n = int(offsets[r]), int(counts[r])
+        sl = slice(b, b + n)
+        alpha = 1.0 - torch.exp(-torch.relu(raw[sl, 3]) * (te[sl] - ts[sl]))
+        T = torch.cat([torch.ones(1, dtype=torch.float64), torch.cumprod(1.0 - alpha, 0)[:-1]]) if n else alpha
+        w = torch.where(T.detach() >= ert_eps, T * alpha, torch.zeros_like(alpha))
+        c = torch.sigmoid(raw[sl, :3])
+        acc = w.sum()
+        rgbs.append((w[:, None] * c).sum(0) + ((1.0 - acc) if white_bkgd else 0.0))
+        depths.append((w * 0.5 * (ts[sl] + te[sl])).sum() / torch.clamp(acc, min=float(np.finfo(np.float32).eps)))
+        accs.append(acc)
+    return torch.stack(rgbs), torch.stack(depths), torch.stack(accs)
+
+
+def train_loss(rgb_map: torch.Tensor, alpha_map: torch.Tensor, target_rgb, target_alpha, stage: str, l2_reg: float,
+               sd: dict | None = None, prefix: str = "model."):
+    """``NetworkWrapper.forward`` (src/train/trainers/kilonerf.py:43-61): distillation = mse(teacher_rgb, rgb) +
+    mse(teacher_alpha, alpha) [+ l2_reg * colour regulariser (:52-55)]; fine-tuning = mse(gt_rgb, rgb)."""
+    mse = torch.nn.functional.mse_loss
+    if stage == "distillation":
+        loss = mse(target_rgb.reshape(-1, 3).to(rgb_map.dtype), rgb_map.reshape(-1, 3)) + \
+            mse(target_alpha.reshape(-1, 1).to(alpha_map.dtype), alpha_map.reshape(-1, 1))
+        if l2_reg > 0:
+            reg = 0.0
+            for n in ("view_linears_weights", "view_linears_biases", "rgb_linear_weights", "rgb_linear_biases"):
+                reg = reg + torch.sum(sd[prefix + n].to(rgb_map.dtype) ** 2)
+            loss = loss + l2_reg * reg
+        return loss
+    return mse(target_rgb.reshape(-1, 3).to(rgb_map.dtype), rgb_map.reshape(-1, 3))
 
 
 def render(sd: dict, rays_o, rays_d, occ, aabb_min, aabb_max, res, t_near, t_far, step, ert_eps, white_bkgd):

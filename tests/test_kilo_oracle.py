@@ -94,3 +94,51 @@ def test_bake_points_layout():
     assert np.allclose(pts[1, 13] - pts[0, 13], [0, 0, 0.25])                     # k is the fastest cell index
     assert np.allclose(pts[0, 1] - pts[0, 0], [0, 0, 0.25 * 0.25])                # z offset is the fastest sub index
     assert np.allclose(pts[63, 13], np.array([1, 1, 1]) - cell / 2)
+
+
+def test_network_gradients_match_reference_autograd(golden):
+    """Autograd through the oracle's restatement == autograd through the real reference network (fixture)."""
+    from nerf_amd.weights import KILO_TENSORS
+    fx, gx = golden("kilo_network"), golden("kilo_network_grad")
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in _sd(fx).items()}
+    raw = K.network_forward(sd, torch.from_numpy(fx["pts"]), torch.from_numpy(fx["dirs"]), AABB_MIN, AABB_MAX, RES)
+    (raw * torch.from_numpy(gx["grad_raw"])).sum().backward()
+    cells = gx["cells"]
+    for name, _, _ in KILO_TENSORS:
+        g = sd["model." + name].grad
+        ref = gx["grad." + name]
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(g[cells].numpy() - ref).max() < 2e-5 * scale, name
+        assert abs(float(g.double().sum()) - float(gx["sum." + name])) < 1e-5 * float(gx["abssum." + name]), name
+        assert abs(float(g.double().abs().sum()) - float(gx["abssum." + name])) < 1e-5 * float(gx["abssum." + name]), name
+
+
+def test_composite_torch_matches_numpy_rule_and_finite_differences():
+    rng = np.random.default_rng(5)
+    counts = np.array([0, 7, 70, 1, 130], dtype=np.int32)
+    offsets = (np.cumsum(counts) - counts).astype(np.int32)
+    n = int(counts.sum())
+    raw = rng.normal(size=(n, 4)).astype(np.float64)
+    raw[:, 3] = raw[:, 3] * 30 + 10
+    ts = np.concatenate([2.0 + 0.005 * np.arange(c) for c in counts])
+    te = ts + 0.005
+    rgb, depth, acc = K.composite_packed(raw, ts, te, offsets, counts, 0.01, True)
+    t = torch.from_numpy(raw).requires_grad_(True)
+    rgb_t, depth_t, acc_t = K.composite_packed_torch(t, ts, te, offsets, counts, 0.01, True)
+    assert np.abs(rgb_t.detach().numpy() - rgb).max() < 1e-12
+    assert np.abs(depth_t.detach().numpy() - depth).max() < 1e-12
+    assert np.abs(acc_t.detach().numpy() - acc).max() < 1e-12
+    wr, wd, wa = rng.normal(size=rgb.shape), rng.normal(size=depth.shape), rng.normal(size=acc.shape)
+    ((rgb_t * torch.from_numpy(wr)).sum() + (depth_t * torch.from_numpy(wd)).sum() + (acc_t * torch.from_numpy(wa)).sum()).backward()
+    g = t.grad.numpy()
+
+    def f(x):
+        a, b, c = K.composite_packed(x, ts, te, offsets, counts, 0.01, True)
+        return (a * wr).sum() + (b * wd).sum() + (c * wa).sum()
+
+    for i in rng.choice(n, 12, replace=False):
+        for ch in (0, 3):
+            e = np.zeros_like(raw)
+            e[i, ch] = 1e-6
+            fd = (f(raw + e) - f(raw - e)) / 2e-6
+            assert abs(fd - g[i, ch]) < 1e-5 * max(1.0, abs(fd)), (i, ch, fd, g[i, ch])

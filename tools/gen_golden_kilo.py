@@ -67,3 +67,31 @@ np.savez_compressed(os.path.join(OUT, "kilo_network.npz"), pts=p2.numpy(), dirs=
                     sigma=sigma.numpy(), rgb_rays=rgb3.numpy(), sigma_rays=sigma3.numpy(), color_reg_loss=float(reg),
                     weight_seed=7, density_gain=20.0, density_bias=1.0)
 print("kilo_network", rgb.shape, sigma.shape, float(reg), float(sigma.mean()))
+
+# ---- parameter gradients of the tiny MLPs (autograd through BatchedKiloNeRF.forward, network.py:123-167) ----
+# loss = sum(cat([rgb, sigma]) * G) for a fixed upstream gradient G, so param.grad = (d raw / d param)^T G.
+# Stored: the full gradient rows of a few cells (the crowded ones + some with a single point) and float64
+# sums / absolute sums per tensor over ALL cells.
+net.zero_grad()
+for p_ in net.parameters():
+    p_.requires_grad_(True)
+G = torch.randn(P, 4, generator=g).float()
+rgb_g, sigma_g = net(p2, d2)
+loss = (torch.cat([rgb_g.reshape(P, 3), sigma_g.reshape(P, 1)], -1) * G).sum()
+loss.backward()
+with torch.no_grad():
+    i3 = net._get_index(p2)
+    flat2 = (i3[:, 0] * 256 + i3[:, 1] * 16 + i3[:, 2]).numpy()
+cells, cnt = np.unique(flat2, return_counts=True)
+order = np.argsort(-cnt)
+pick = np.concatenate([cells[order[:4]], cells[order[-4:]]]).astype(np.int64)
+from nerf_amd.weights import KILO_TENSORS  # noqa: E402
+named = dict(net.named_parameters())
+out = {"grad_raw": G.numpy(), "cells": pick, "cell_counts": np.array([int((flat2 == c).sum()) for c in pick])}
+for name, _, _ in KILO_TENSORS:
+    gr = named["model." + name].grad
+    out["grad." + name] = gr[pick].numpy()
+    out["sum." + name] = np.float64(gr.double().sum())
+    out["abssum." + name] = np.float64(gr.double().abs().sum())
+np.savez_compressed(os.path.join(OUT, "kilo_network_grad.npz"), **out)
+print("kilo_network_grad cells", pick, out["cell_counts"], {k: float(v) for k, v in out.items() if k.startswith("abssum.")})
