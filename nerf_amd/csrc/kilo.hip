@@ -101,7 +101,7 @@ __global__ void kilo_route_kernel(Grid g, const float* __restrict__ pts, int64_t
 }
 
 // single block: exclusive scan of the per-cell counts -> segment starts, cursors and the job prefix
-__global__ void kilo_cell_scan_kernel(const int* __restrict__ hist, int ncell, int* __restrict__ seg_start,
+__global__ void kilo_cell_scan_kernel(const int* __restrict__ hist, int ncell, int job_tiles, int* __restrict__ seg_start,
                                       int* __restrict__ cursor, int* __restrict__ job_prefix) {
     __shared__ int s_a[1024], s_b[1024];
     const int tid = threadIdx.x;
@@ -111,7 +111,7 @@ __global__ void kilo_cell_scan_kernel(const int* __restrict__ hist, int ncell, i
         const int c = tid * per + k;
         if (c < ncell) {
             cnt += hist[c];
-            jobs += (hist[c] + 32 * kJobTiles - 1) / (32 * kJobTiles);
+            jobs += (hist[c] + 32 * job_tiles - 1) / (32 * job_tiles);
         }
     }
     s_a[tid] = cnt, s_b[tid] = jobs;
@@ -128,7 +128,7 @@ __global__ void kilo_cell_scan_kernel(const int* __restrict__ hist, int ncell, i
         if (c < ncell) {
             seg_start[c] = a, cursor[c] = a, job_prefix[c] = b;
             a += hist[c];
-            b += (hist[c] + 32 * kJobTiles - 1) / (32 * kJobTiles);
+            b += (hist[c] + 32 * job_tiles - 1) / (32 * job_tiles);
         }
     }
     if (tid == 1023) seg_start[ncell] = s_a[1023], job_prefix[ncell] = s_b[1023];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict
 // so this is the plain form: one wave per SIMD, the cell's whole weight set in registers for the job (24 float4 of
 // matrix operands, biases as accumulator initialisers, head rows), gathers prefetched three tiles ahead.
 template <bool INDEXED>  // directions gathered through dir_index (one per ray) or given per point
-__global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell,
+__global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
                                                           const int* __restrict__ seg_start,
                                                           const int* __restrict__ job_prefix,
                                                           const int* __restrict__ perm, const float* __restrict__ pts,
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restric
         }
         const int cell = lo;
         const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
-        const int first = seg_b + (job - job_prefix[cell]) * 32 * kJobTiles;
+        const int first = seg_b + (job - job_prefix[cell]) * 32 * job_tiles;
         const float* cw = packed + int64_t(cell) * kKiloCellFloats;
         float4 w[kKiloSteps];
 #pragma unroll
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restric
             for (int a = 0; a < 3; ++a) pn[a] = pts[id_n * 3u + a];
             di_n = dir_of(id_n);
         }
-        for (int t0 = first; t0 < seg_e && t0 < first + 32 * kJobTiles; t0 += 32) {
+        for (int t0 = first; t0 < seg_e && t0 < first + 32 * job_tiles; t0 += 32) {
             const bool valid = t0 + j < seg_e;
             const unsigned id = id_c;
             const float px = pc[0], py = pc[1], pz = pc[2], dx = dc[0], dy = dc[1], dz = dc[2];
@@ -490,13 +490,16 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
     const int64_t blocks = (n_points + 255) / 256;
     const unsigned rb = unsigned(blocks < 2048 ? blocks : 2048);
     kilo_route_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(g, pts, n_points, cell, hist);
-    kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, seg_start, cursor, job_prefix);
+    // tiles of one cell per weight load: up to kJobTiles, fewer for small batches so that every wavefront gets jobs
+    int64_t jt = (n_points + 32 * 4 * int64_t(cus) * 4 - 1) / (32 * 4 * int64_t(cus) * 4);
+    const int job_tiles = int(jt < 4 ? 4 : jt > kJobTiles ? kJobTiles : jt);
+    kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, job_tiles, seg_start, cursor, job_prefix);
     kilo_scatter_kernel<<<dim3(rb), 256, 0, stream>>>(cell, n_points, cursor, perm);
     if (dir_index)
-        kilo_mlp_kernel<true><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, seg_start, job_prefix, perm, pts,
+        kilo_mlp_kernel<true><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
                                                                        dirs, dir_index, reinterpret_cast<float4*>(raw));
     else
-        kilo_mlp_kernel<false><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, seg_start, job_prefix, perm, pts,
+        kilo_mlp_kernel<false><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
                                                                         dirs, dir_index, reinterpret_cast<float4*>(raw));
     return nrf_launch_status();
 }

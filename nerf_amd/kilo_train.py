@@ -19,6 +19,7 @@ from __future__ import annotations
 import torch
 
 from . import kilo_ops, ops
+from .parallel import allreduce_gradients
 from .weights import KILO_TENSORS
 
 _REG_TENSORS = ("view_linears_weights", "view_linears_biases", "rgb_linear_weights", "rgb_linear_biases")
@@ -91,10 +92,9 @@ class KiloTrainStep:
 
     def step(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation"):
         out = self.forward_backward(rays_o, rays_d, target_rgb, target_alpha, stage)
-        if self.world > 1:   # DDP semantics: mean of per-rank gradients; ONE flat sum all-reduce over RCCL
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        scale = allreduce_gradients(self.grad, self.group)   # DDP semantics: ONE flat sum all-reduce, mean in the kernel
         self.t += 1
         ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.t, lr=self.lr, clip_value=self.clip,
-                      grad_scale=1.0 / self.world)
+                      grad_scale=scale)
         self.net._packed_key = None   # the in-place update does not bump tensor versions: drop the inference pack
         return out

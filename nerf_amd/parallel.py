@@ -27,6 +27,21 @@ def view_schedule(n_views: int, rank: int, world: int, tiles_per_view: int = 1):
     return items[rank::world]
 
 
+def allreduce_gradients(flat_grad: torch.Tensor, group=None) -> float:
+    """Data-parallel gradient exchange of the training steps (``trainer.py:14-21`` DDP semantics: every rank has
+    its own batch, parameters move by the MEAN gradient): ONE sum all-reduce of the flat gradient buffer (RCCL
+    over xGMI on the GPU box, gloo in the CPU tests).  Returns the factor the optimiser kernel must apply to the
+    summed gradient (1 / world); the division itself is fused into ``nrf_clip_adam`` (before the +-40 clamp, as
+    DDP averages before ``clip_grad_value_``)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
 def render_frame_sharded(render_rows, n_rays: int, rank: int, world: int, group=None, gather: bool = True):
     """Render rays ``shard_range(n_rays, rank, world)`` with ``render_rows(first_ray, count) -> dict`` of
     per-ray tensors ((count, C) or (count,)), and, if ``gather``, assemble all ranks' slices in ray

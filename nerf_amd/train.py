@@ -16,6 +16,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from .parallel import allreduce_gradients
 from .renderer import near_far_table
 
 
@@ -84,9 +85,8 @@ class TrainStep:
 
     def step(self, rays_o, rays_d, gt, u, u2, u_coarse=None, u_fine=None):
         out = self.forward_backward(rays_o, rays_d, gt, u, u2, u_coarse, u_fine)
-        if self.world > 1:   # DDP semantics: mean of per-rank gradients; ONE flat sum all-reduce over RCCL
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        scale = allreduce_gradients(self.grad, self.group)   # DDP semantics: ONE flat sum all-reduce, mean in the kernel
         self.t += 1
         ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.t, lr=self.lr, clip_value=self.clip,
-                      grad_scale=1.0 / self.world)
+                      grad_scale=scale)
         return out

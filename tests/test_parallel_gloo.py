@@ -57,3 +57,50 @@ def test_two_rank_frame_assembly(n_rays):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _grad_worker(rank, world, port, q):
+    """The training steps' gradient exchange: per-rank flat gradients -> identical sums on every rank and the
+    1/world factor the fused clip+Adam kernel applies (here applied on the CPU to check the update)."""
+    from nerf_amd.parallel import allreduce_gradients
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1191688                                             # both NeRF models, SURVEY 8a row 12
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(n, generator=g)
+        flat = local.clone()
+        scale = allreduce_gradients(flat)
+        others = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        mean = sum(others) / world
+        ok = scale == 1.0 / world and torch.allclose(flat * scale, mean, atol=1e-6)
+        # the reference order: mean over ranks, then clip_grad_value_(40), then Adam (trainer.py:73-75)
+        p = torch.zeros(n, requires_grad=True)
+        p.grad = (flat * scale * 30).clone()
+        torch.nn.utils.clip_grad_value_([p], 40.0)
+        torch.optim.Adam([p], lr=5e-4).step()
+        gathered = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(gathered, p.detach())
+        ok = ok and all(torch.equal(gathered[0], t) for t in gathered)      # replicas stay bit-identical
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_mean():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_allreduce_gradients_without_process_group_is_identity():
+    from nerf_amd.parallel import allreduce_gradients
+    g = torch.arange(5, dtype=torch.float32)
+    assert allreduce_gradients(g) == 1.0 and torch.equal(g, torch.arange(5, dtype=torch.float32))
