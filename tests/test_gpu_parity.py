@@ -277,3 +277,31 @@ def test_distillation_records(dev, tmp_path):
     torch.manual_seed(5)
     out = r.render({"xyz": o[None], "viewdirs": d[None], "gt_rgb": o[None]}, is_training=False)
     assert torch.equal(out["fine_rgb_map"].cpu(), rec["teacher_rgb"])
+
+
+def test_checkpoint_render_and_psnr(dev, tmp_path):
+    """a checkpoint in the reference's format -> fresh Network -> HIP render -> evaluator PSNR."""
+    from nerf_amd import checkpoint as ckpt, ops
+    from nerf_amd.camera import focal_from_angle, test_set_poses
+    from nerf_amd.config import default_cfg
+    from nerf_amd.network import Network
+    from nerf_amd.renderer import Renderer
+    from nerf_amd.weights import make_state_dict
+    a = Network()
+    a.load_state_dict(make_state_dict(2, 30.0, 2.0))
+    ckpt.save_model(a, str(tmp_path), 199, last=True)
+    b = Network().to(dev)
+    assert ckpt.load_network(b, str(tmp_path), map_location=dev) == 200
+    H = W = 16
+    o, d = ops.raygen(test_set_poses(200)[7], H, W, focal_from_angle(W), dev)
+    gt = torch.rand(H * W, 3, device=dev)
+    batch = {"xyz": o[None], "viewdirs": d[None], "gt_rgb": gt[None], "H": torch.tensor(H), "W": torch.tensor(W)}
+    outs = []
+    for net in (a.to(dev), b):
+        torch.manual_seed(11)
+        outs.append(Renderer(net, default_cfg(perturb=0)).render(batch, is_training=False))
+    assert torch.equal(outs[0]["fine_rgb_map"], outs[1]["fine_rgb_map"])
+    ev = ckpt.Evaluator()
+    ev.evaluate(outs[1], batch)
+    want = -10 * np.log10(np.mean((outs[1]["fine_rgb_map"].cpu().numpy() - gt.cpu().numpy()) ** 2))
+    assert abs(ev.summarize()["mean_psnr"] - want) < 1e-4
