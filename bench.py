@@ -322,12 +322,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # One rank per GPU.  NRF_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks (ranks then
+    # share devices and the timing collectives run over gloo); the measured configuration is always nccl = RCCL.
+    backend = os.environ.get("NRF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://")
 
     from nerf_amd import ops
     from nerf_amd.camera import test_set_poses, focal_from_angle

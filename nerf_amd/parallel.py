@@ -38,7 +38,12 @@ def allreduce_gradients(flat_grad: torch.Tensor, group=None) -> float:
         return 1.0
     world = dist.get_world_size(group)
     if world > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+        if flat_grad.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal / CPU-only transport: stage through host
+            host = flat_grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat_grad.copy_(host)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
 
 
