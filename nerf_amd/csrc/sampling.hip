@@ -40,6 +40,68 @@ __global__ __launch_bounds__(256) void perturb_kernel(const float* __restrict__ 
     z_out[idx] = perturb_one(prev, cur, next, i == 0, i + 1 == n, u[idx]);
 }
 
+// ---- cross-lane exchange for the register sort: value of lane (lane ^ MASK) ------------------
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v) {
+    const int x = __float_as_int(v);
+    int r;
+    if constexpr (MASK == 1) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, true);         // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 3) r = __builtin_amdgcn_update_dpp(x, x, 0x1B, 0xf, 0xf, true);    // quad_perm [3,2,1,0]
+    else if constexpr (MASK == 7) r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    else if constexpr (MASK == 15) r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, true);  // row_mirror
+    else if constexpr (MASK == 8) r = __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, true);   // row_ror:8
+    else if constexpr (MASK == 4 || MASK == 16 || MASK == 31)
+        r = __builtin_amdgcn_ds_swizzle(x, 0x1f | (MASK << 10));                                  // bit-mask mode: lane ^ MASK
+    else r = __shfl_xor(x, MASK);
+    return __int_as_float(r);
+}
+
+// One compare-exchange stage of the ascending bitonic network over 256 keys, 4 per lane (key index = 4 * lane + r).
+// MASK = lane distance (xor), REV: the partner holds the key in register 3 - r (mirror step).  The lane with the
+// smaller index keeps the minimum: med3(a, b, -inf) = min, med3(a, b, +inf) = max, `sel` = -+inf by lane bit.
+template <int MASK, bool REV>
+__device__ __forceinline__ void sort_stage_lanes(float (&e)[4], float sel) {
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = lane_xor<MASK>(e[REV ? 3 - r : r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], p[r], sel);
+}
+__device__ __forceinline__ void cx(float& a, float& b) {
+    const float lo = fminf(a, b), hi = fmaxf(a, b);
+    a = lo, b = hi;
+}
+__device__ __forceinline__ void sort_tail(float (&e)[4]) {  // key distances 2 and 1: inside the lane
+    cx(e[0], e[2]), cx(e[1], e[3]);
+    cx(e[0], e[1]), cx(e[2], e[3]);
+}
+
+// sort(cat(coarse, fine)) (:288-289), values only, so any assignment of the keys to (lane, register) slots will do:
+// no staging.  36 compare-exchange stages, 21 of them across lanes (DPP / swizzle), ~230 VALU instructions.
+__device__ __forceinline__ void sort256(float (&e)[4], int lane) {
+    const float ninf = -__builtin_inff(), pinf = __builtin_inff();
+    const float s1 = lane & 1 ? pinf : ninf, s2 = lane & 2 ? pinf : ninf, s4 = lane & 4 ? pinf : ninf;
+    const float s8 = lane & 8 ? pinf : ninf, s16 = lane & 16 ? pinf : ninf, s32 = lane & 32 ? pinf : ninf;
+    cx(e[0], e[1]), cx(e[2], e[3]);                                   // k = 2
+    cx(e[0], e[3]), cx(e[1], e[2]), cx(e[0], e[1]), cx(e[2], e[3]);   // k = 4: mirror, then distance 1
+    sort_stage_lanes<1, true>(e, s1), sort_tail(e);                                                  // k = 8
+    sort_stage_lanes<3, true>(e, s2), sort_stage_lanes<1, false>(e, s1), sort_tail(e);               // k = 16
+    sort_stage_lanes<7, true>(e, s4), sort_stage_lanes<2, false>(e, s2), sort_stage_lanes<1, false>(e, s1), sort_tail(e);
+    sort_stage_lanes<15, true>(e, s8), sort_stage_lanes<4, false>(e, s4), sort_stage_lanes<2, false>(e, s2);
+    sort_stage_lanes<1, false>(e, s1), sort_tail(e);                                                 // k = 64
+    sort_stage_lanes<31, true>(e, s16), sort_stage_lanes<8, false>(e, s8), sort_stage_lanes<4, false>(e, s4);
+    sort_stage_lanes<2, false>(e, s2), sort_stage_lanes<1, false>(e, s1), sort_tail(e);              // k = 128
+    sort_stage_lanes<63, true>(e, s32), sort_stage_lanes<16, false>(e, s16), sort_stage_lanes<8, false>(e, s8);
+    sort_stage_lanes<4, false>(e, s4), sort_stage_lanes<2, false>(e, s2), sort_stage_lanes<1, false>(e, s1), sort_tail(e);
+}
+
+__device__ __forceinline__ double shfl_up_f64(double v, int off) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_up(int(b), off), hi = __shfl_up(int(b >> 32), off);
+    return __longlong_as_double((long long)(unsigned(lo)) | ((long long)hi << 32));
+}
+
 template <int NI>  // n_importance = 64 * NI
 __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restrict__ weights, const float* __restrict__ bins,
                                                           int64_t bins_stride, const float* __restrict__ z_coarse,
@@ -50,17 +112,18 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     constexpr int NC = 64, NIMP = 64 * NI, NOUT = NC + NIMP;
     __shared__ float s_cdf[4][80];
     __shared__ float s_bins[4][64];
-    __shared__ float s_sort[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ray = int64_t(blockIdx.x) * 4 + wv;
     if (ray >= n_rays) return;  // wave-uniform; LDS regions are wave-private, no block barrier used
     float* cdf = s_cdf[wv];
     float* sbin = s_bins[wv];
-    float* srt = s_sort[wv];
 
     const float w = weights[ray * NC + lane];
     sbin[lane] = bins[ray * bins_stride + lane];
-    srt[lane] = z_coarse[ray * zc_stride + lane];
+    const float zc = z_coarse[ray * zc_stride + lane];
+    float uu[NI], uv[NI];
+#pragma unroll
+    for (int c = 0; c < NI; ++c) uu[c] = u[ray * NIMP + c * 64 + lane], uv[c] = u2[ray * NIMP + c * 64 + lane];
 
     // ---- sum(w): torch-CPU cascade.  v[i] = x[i] + x[32+i]; lane partial l = ((v[l]+v[8+l])+v[16+l])+v[24+l];
     //      total = (((0 + L0) + L1) + ... + L7)                                   (volume_renderer.py:374)
@@ -73,14 +136,34 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     for (int l = 0; l < 8; ++l) tot = __fadd_rn(tot, __shfl(part, l));
     const float pdf = __fdiv_rn(w, __fadd_rn(tot, 1e-10f));
 
-    // ---- cdf = [0, cumsum(pdf)]: sequential fp64 running sum, prefix k rounded to fp32 (:375-376)
-    double acc = 0.0;
+    // ---- cdf = [0, cumsum(pdf)] (:375-376).  The reference's prefix k is a SEQUENTIAL fp64 running sum rounded to
+    //      fp32.  A 6-step fp64 wave scan adds the same non-negative terms in another order: the two sums differ by
+    //      at most ~64 ulp64 (1.4e-14 relative), so they round to the same fp32 unless the scan result lies within
+    //      that distance of a rounding boundary (the mid-point to a neighbouring float).  Such rays (and rays with a
+    //      negative or NaN term, where the bound does not hold) take the sequential path; probability ~2e-4 per ray.
+    double run = double(pdf);
 #pragma unroll
-    for (int jj = 0; jj < 64; ++jj) {
-        const float pj = __shfl(pdf, jj);
-        acc = __dadd_rn(acc, jj <= lane ? double(pj) : 0.0);
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = shfl_up_f64(run, off);
+        if (lane >= off) run = __dadd_rn(run, t);
     }
-    cdf[lane + 1] = float(acc);
+    float cdf_k = float(run);
+    bool risky = !(pdf >= 0.f);
+    if (run != 0.0) {
+        const unsigned b = __float_as_uint(cdf_k);
+        const double fu = double(__uint_as_float(b + 1u)), fd = double(__uint_as_float(b ? b - 1u : b)), f = double(cdf_k);
+        const double margin = 1e-13 * run;
+        risky = risky || fabs(run - 0.5 * (f + fu)) <= margin || fabs(run - 0.5 * (f + fd)) <= margin;
+    }
+    if (__any(risky)) {
+        double acc = 0.0;
+        for (int jj = 0; jj < 64; ++jj) {
+            const float pj = __shfl(pdf, jj);
+            acc = __dadd_rn(acc, jj <= lane ? double(pj) : 0.0);
+        }
+        cdf_k = float(acc);
+    }
+    cdf[lane + 1] = cdf_k;
     if (lane == 0) cdf[0] = 0.f;
     wave_sync();
 
@@ -89,68 +172,53 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
         const int i = c * 64 + lane;
-        const float uu = u[ray * NIMP + i];
         int lo = 0, hi = NC + 1;  // upper bound over the 65 cdf entries
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
             if (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+                if (cdf[mid] <= uu[c]) lo = mid + 1; else hi = mid;
             }
         }
         int idx = lo - 1;
         idx = idx < 0 ? 0 : (idx > NC - 1 ? NC - 1 : idx);
         const float b_lo = sbin[idx];
         const float b_hi = sbin[idx + 1 > NC - 1 ? NC - 1 : idx + 1];
-        fine[c] = __fadd_rn(b_lo, __fmul_rn(__fsub_rn(b_hi, b_lo), u2[ray * NIMP + i]));
+        fine[c] = __fadd_rn(b_lo, __fmul_rn(__fsub_rn(b_hi, b_lo), uv[c]));
         if (idx_out) idx_out[ray * NIMP + i] = idx;
-        srt[NC + i] = fine[c];
     }
-    if (u_fine) {  // add_perturbation on the (unsorted) fine samples, render_fine :283-284
-        wave_sync();
+    if (u_fine) {  // add_perturbation on the (unsorted) fine samples, render_fine :283-284; sample i = c * 64 + lane
         float pf[NI];
 #pragma unroll
         for (int c = 0; c < NI; ++c) {
-            const int i = c * 64 + lane;
-            const float prev = i > 0 ? srt[NC + i - 1] : fine[c];
-            const float next = i + 1 < NIMP ? srt[NC + i + 1] : fine[c];
-            pf[c] = perturb_one(prev, fine[c], next, i == 0, i + 1 == NIMP, u_fine[ray * NIMP + i]);
+            // neighbours in sample order; shuffles stay outside divergent code
+            const float last_of_prev = c > 0 ? __shfl(fine[c > 0 ? c - 1 : 0], 63) : fine[c];
+            const float first_of_next = c + 1 < NI ? __shfl(fine[c + 1 < NI ? c + 1 : c], 0) : fine[c];
+            float prev = __shfl_up(fine[c], 1), next = __shfl_down(fine[c], 1);
+            if (lane == 0) prev = last_of_prev;
+            if (lane == 63) next = first_of_next;
+            pf[c] = perturb_one(prev, fine[c], next, c == 0 && lane == 0, c == NI - 1 && lane == 63,
+                                u_fine[ray * NIMP + c * 64 + lane]);
         }
-        wave_sync();
 #pragma unroll
-        for (int c = 0; c < NI; ++c) {
-            fine[c] = pf[c];
-            srt[NC + c * 64 + lane] = pf[c];
-        }
+        for (int c = 0; c < NI; ++c) fine[c] = pf[c];
     }
     if (fine_out) {
 #pragma unroll
         for (int c = 0; c < NI; ++c) fine_out[ray * NIMP + c * 64 + lane] = fine[c];
     }
-#pragma unroll
-    for (int i = NOUT + lane; i < 256; i += 64) srt[i] = __builtin_inff();
-    wave_sync();
 
-    // ---- sort(cat(coarse, fine)) (:288-289): bitonic network over 256 LDS slots, 2 pairs per lane per stage
-    for (int k = 2; k <= 256; k <<= 1) {
-        for (int jd = k >> 1; jd > 0; jd >>= 1) {
+    // ---- sort(cat(coarse, fine)) (:288-289) in registers; key 4 * lane + r comes out in ascending order
+    float e[4];
+    e[0] = zc;
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int p = lane + 64 * pp;
-                const int i = ((p & ~(jd - 1)) << 1) | (p & (jd - 1));
-                const int q = i | jd;
-                const float a = srt[i], b = srt[q];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    srt[i] = b;
-                    srt[q] = a;
-                }
-            }
-            wave_sync();
-        }
+    for (int c = 0; c < 3; ++c) e[1 + c] = c < NI ? fine[c < NI ? c : 0] : __builtin_inff();
+    sort256(e, lane);
+    if (4 * lane < NOUT) {
+        float* dst = z_out + ray * NOUT + 4 * lane;
+        if ((reinterpret_cast<uintptr_t>(z_out) & 15u) == 0) *reinterpret_cast<float4*>(dst) = make_float4(e[0], e[1], e[2], e[3]);
+        else dst[0] = e[0], dst[1] = e[1], dst[2] = e[2], dst[3] = e[3];
     }
-#pragma unroll
-    for (int i = lane; i < NOUT; i += 64) z_out[ray * NOUT + i] = srt[i];
 }
 
 }  // namespace

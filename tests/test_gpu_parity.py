@@ -303,5 +303,33 @@ def test_checkpoint_render_and_psnr(dev, tmp_path):
     assert torch.equal(outs[0]["fine_rgb_map"], outs[1]["fine_rgb_map"])
     ev = ckpt.Evaluator()
     ev.evaluate(outs[1], batch)
-    want = -10 * np.log10(np.mean((outs[1]["fine_rgb_map"].cpu().numpy() - gt.cpu().numpy()) ** 2))
+    want = -10 * np.log10(np.mean((outs[1]["fine_rgb_map"].detach().cpu().numpy() - gt.cpu().numpy()) ** 2))
     assert abs(ev.summarize()["mean_psnr"] - want) < 1e-4
+
+
+@pytest.mark.parametrize("n_imp,n_rays", [(128, 200000), (64, 20000), (192, 20000)])
+def test_sample_fine_bit_exact_at_scale(dev, n_imp, n_rays):
+    """Bit-exactness of the resampling + merge sort on many random rays: the fp64 wave-scan CDF with its
+    rounding-boundary guard must agree with the sequential running sum of the reference everywhere (a guard that
+    never fired would show up as ~1 wrong prefix per 5 M), and the register sort with np.sort."""
+    from nerf_amd import ops
+    from oracle import nerf_oracle as O
+    rng = np.random.default_rng(n_imp)
+    bins = O.t_bins(2.0, 6.0, 64)
+    w = rng.uniform(size=(n_rays, 64)).astype(np.float32) ** 8                 # peaky, like real coarse weights
+    w[rng.uniform(size=(n_rays, 64)) < 0.5] = 0
+    w[:100] = 0                                                                 # all-zero rows: every sample = far
+    w[100:200, 1:] = 0                                                          # one-hot rows
+    w[200:300] = np.float32(1e-30) * w[200:300]                                 # tiny weights
+    u = rng.uniform(size=(n_rays, n_imp)).astype(np.float32)
+    u2 = rng.uniform(size=(n_rays, n_imp)).astype(np.float32)
+    u[300:310, :4] = [0.0, np.nextafter(np.float32(1), np.float32(0)), 0.5, 0.25]
+    zc = ops.perturb_samples(_t(bins, dev), _t(rng.uniform(size=(n_rays, 64)).astype(np.float32), dev))
+    z, fine, idx = ops.sample_fine(_t(w, dev), _t(bins, dev), zc, _t(u, dev), _t(u2, dev), want_debug=True)
+    z, fine, idx, zc = z.cpu().numpy(), fine.cpu().numpy(), idx.cpu().numpy(), zc.cpu().numpy()
+    for b in range(0, n_rays, 16384):
+        sl = slice(b, min(b + 16384, n_rays))
+        f_ref, i_ref = O.importance_sampling(w[sl], bins, u[sl], u2[sl])
+        assert np.array_equal(idx[sl].astype(np.int64), i_ref)
+        assert np.array_equal(fine[sl], f_ref)
+        assert np.array_equal(z[sl], O.merge_sort(zc[sl], f_ref))
