@@ -36,3 +36,44 @@ def generate(renderer, poses, H: int, W: int, focal: float, out_dir: str, device
         save(distill_view(renderer, poses[view], H, W, focal, device), path)
         paths.append(path)
     return paths
+
+
+class DistRecords:
+    """The reader side: ``DistDataset`` of /root/reference/src/datasets/kilonerf/blender.py:168-220.  All ``.pt``
+    records of ``data_root`` (sorted by name, :183-187) are loaded once (``torch.load(weights_only=True)``) and
+    kept on ``device`` -- 100 full 800x800 views are 2.6 GB, nothing next to 288 GB of HBM, so a training batch is
+    an index_select on the GPU instead of a DataLoader worker + H2D copy.  ``self[i]`` is one item (``N_rays``
+    rays of view i drawn without replacement, :207-217); ``batch(view_ids)`` stacks items the way the DataLoader's
+    collate does: every key ``(B, N_rays, C)``."""
+
+    KEYS = ("xyz", "viewdirs", "teacher_rgb", "teacher_alpha")
+
+    def __init__(self, data_root: str, n_rays: int = 1024, device="cpu", generator: torch.Generator | None = None):
+        self.files = sorted(os.path.join(data_root, f) for f in os.listdir(data_root) if f.endswith(".pt"))
+        if not self.files:
+            raise FileNotFoundError(f"No distilled data (.pt files) found in {data_root}")   # :189-190
+        self.n_rays = int(n_rays)
+        self.device = torch.device(device)
+        self.generator = generator
+        self.records = []
+        for path in self.files:
+            rec = torch.load(path, map_location="cpu", weights_only=True)
+            missing = [k for k in self.KEYS if k not in rec]
+            if missing:
+                raise KeyError(f"{path}: missing {missing}")
+            self.records.append({k: rec[k].to(self.device) for k in self.KEYS})
+
+    def __len__(self):
+        return len(self.files)                                # one item per original image (:199-201)
+
+    def __getitem__(self, index: int) -> dict:
+        rec = self.records[index]
+        n = rec["xyz"].shape[0]
+        if self.n_rays > n:
+            raise ValueError(f"record {index} has {n} rays, fewer than N_rays = {self.n_rays}")
+        sel = torch.randperm(n, device=self.device, generator=self.generator)[: self.n_rays]
+        return {k: rec[k].index_select(0, sel) for k in self.KEYS}
+
+    def batch(self, view_ids) -> dict:
+        items = [self[int(i)] for i in view_ids]
+        return {k: torch.stack([it[k] for it in items], 0) for k in self.KEYS}
