@@ -273,6 +273,9 @@ typedef struct nrf_render_args {
 
 int64_t nrf_render_workspace_bytes(int64_t n_rays, int n_coarse, int n_importance);
 int nrf_render(const nrf_render_args* args, nrf_stream_t stream);
+/* The same path with bf16 MLPs: packed_coarse / packed_fine are nrf_pack_weights_bf16 streams (cast to const float*),
+ * everything else as above (compositing, resampling and all outputs stay fp32). */
+int nrf_render_bf16(const nrf_render_args* args, nrf_stream_t stream);
 
 #ifdef __cplusplus
 }

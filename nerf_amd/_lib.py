@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnerf_amd.so")
 SYMBOLS = (
     "nrf_version", "nrf_strerror", "nrf_packed_floats", "nrf_pack_weights", "nrf_raygen",
     "nrf_perturb_samples", "nrf_mlp_forward_rays", "nrf_mlp_forward_points", "nrf_composite",
-    "nrf_sample_fine", "nrf_render_workspace_bytes", "nrf_render",
+    "nrf_sample_fine", "nrf_render_workspace_bytes", "nrf_render", "nrf_render_bf16",
     "nrf_packed_bwd_floats", "nrf_pack_weights_transposed", "nrf_mlp_train_tiles", "nrf_mlp_acts_bytes",
     "nrf_mlp_masks_bytes", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_model_param_floats",
     "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mse_grad", "nrf_clip_adam",
@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
     L.nrf_render_workspace_bytes.restype = I64
     L.nrf_render_workspace_bytes.argtypes = [I64, INT, INT]
     L.nrf_render.argtypes = [C.POINTER(RenderArgs), P]
+    L.nrf_render_bf16.argtypes = [C.POINTER(RenderArgs), P]
+    L.nrf_render_bf16.restype = INT
     L.nrf_packed_bwd_floats.restype = I64
     L.nrf_pack_weights_transposed.argtypes = [P, P, P]
     for name in ("nrf_mlp_train_tiles", "nrf_mlp_acts_bytes", "nrf_mlp_masks_bytes", "nrf_mlp_backward_workspace_bytes"):

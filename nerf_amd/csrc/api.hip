@@ -40,7 +40,7 @@ NRF_EXPORT int64_t nrf_render_workspace_bytes(int64_t n_rays, int n_coarse, int 
     return Workspace(n_rays, n_coarse, n_importance).total;
 }
 
-NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) {
+static int render_path(const nrf_render_args* a, bool bf16, nrf_stream_t stream) {
     if (!a) return NRF_ERR_NULL;
     if (!a->packed_coarse || !a->packed_fine || !a->rays_o || !a->rays_d || !a->bins || !a->u || !a->u2 ||
         !a->coarse_rgb || !a->coarse_depth || !a->fine_rgb || !a->fine_depth || !a->fine_acc || !a->workspace)
@@ -68,8 +68,11 @@ NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) {
         zc = zc_buf;
         zc_stride = nc;
     }
-    if ((st = nrf_mlp_forward_rays(a->packed_coarse, a->rays_o, a->rays_d, zc, zc_stride, a->n_rays, nc, raw, stream)))
-        return st;
+    auto mlp = [&](const float* packed, const float* z, int64_t z_stride, int n_samples) {
+        return bf16 ? nrf_mlp_forward_rays_bf16(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream)
+                    : nrf_mlp_forward_rays(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
+    };
+    if ((st = mlp(a->packed_coarse, zc, zc_stride, nc))) return st;
     if ((st = nrf_composite(raw, zc, zc_stride, a->n_rays, nc, a->white_bkgd, a->coarse_rgb, a->coarse_depth, acc_c, w_c,
                             stream)))
         return st;
@@ -77,8 +80,13 @@ NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) {
     if ((st = nrf_sample_fine(w_c, a->bins, 0, zc, zc_stride, a->u, a->u2, a->u_fine, a->n_rays, nc, ni, z_f, nullptr,
                               nullptr, stream)))
         return st;
-    if ((st = nrf_mlp_forward_rays(a->packed_fine, a->rays_o, a->rays_d, z_f, nc + ni, a->n_rays, nc + ni, raw, stream)))
-        return st;
+    if ((st = mlp(a->packed_fine, z_f, nc + ni, nc + ni))) return st;
     return nrf_composite(raw, z_f, nc + ni, a->n_rays, nc + ni, a->white_bkgd, a->fine_rgb, a->fine_depth, a->fine_acc,
                          nullptr, stream);
 }
+
+NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, false, stream); }
+
+// Same path with both MLPs evaluated by nrf_mlp_forward_rays_bf16: packed_coarse / packed_fine point at
+// nrf_pack_weights_bf16 streams (BASELINE configs[4]).
+NRF_EXPORT int nrf_render_bf16(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, true, stream); }

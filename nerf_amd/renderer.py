@@ -206,8 +206,6 @@ class Renderer(nn.Module):
             if self.mlp_dtype != "fp32":
                 raise NrfError("training runs the fp32 kernels: construct the Renderer with mlp_dtype='fp32'")
             return self.render_rays_train(rays_o, rays_d, u, u2, u_coarse, u_fine)
-        if self.mlp_dtype == "bf16":   # nrf_render is the fp32 pipeline; the bf16 MLP goes stage by stage
-            return self.render_rays_staged(rays_o, rays_d, u, u2, u_coarse, u_fine)
         return self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
 
     def render_rays_staged(self, rays_o, rays_d, u, u2, u_coarse=None, u_fine=None, events=None):
@@ -254,8 +252,9 @@ class Renderer(nn.Module):
         nc, ni = self.N_samples, self.N_importance
         if self._bins is None or self._bins.device != dev:
             self._bins = torch.from_numpy(near_far_table(self.near, self.far, nc)).to(dev)
-        pc = self._packed_model("model", dev)
-        pf = self._packed_model("model_fine", dev)
+        bf16 = self.mlp_dtype == "bf16"
+        pc = self._packed_model("model", dev, bf16)
+        pf = self._packed_model("model_fine", dev, bf16)
         c_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
         c_depth = torch.empty((R,), dtype=torch.float32, device=dev)
         f_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
@@ -282,7 +281,7 @@ class Renderer(nn.Module):
                 a.coarse_rgb, a.coarse_depth = c_rgb[r0:].data_ptr(), c_depth[r0:].data_ptr()
                 a.fine_rgb, a.fine_depth, a.fine_acc = f_rgb[r0:].data_ptr(), f_depth[r0:].data_ptr(), f_acc[r0:].data_ptr()
                 a.workspace, a.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
-                check(L.nrf_render(C.byref(a), stream), "nrf_render")
+                check((L.nrf_render_bf16 if bf16 else L.nrf_render)(C.byref(a), stream), "nrf_render")
         return {
             "coarse_rgb_map": c_rgb, "coarse_depth_map": c_depth,
             "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc,

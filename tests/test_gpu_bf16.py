@@ -73,6 +73,11 @@ def test_render_bf16_end_to_end_vs_fp32_reference(golden, dev, name):
         err = float(np.abs(out[k].cpu().numpy() - fx[k]).max())
         print(name, k, err)
         assert err < tol, (k, err)
+    # the whole-path entry point (nrf_render_bf16) runs the same kernels in the same order: identical bits
+    with torch.no_grad():
+        whole = r.render_rays(_t(fx["xyz"], dev), _t(fx["viewdirs"], dev), _t(fx["u"], dev), _t(fx["u2"], dev))
+    for k in ("coarse_rgb_map", "fine_rgb_map", "alpha_map", "coarse_depth_map", "fine_depth_map"):
+        assert torch.equal(whole[k].reshape(-1), out[k].reshape(-1)), k
 
 
 def test_bf16_argument_checks(dev):
