@@ -44,10 +44,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", default="render", choices=["render", "train", "kilo", "kilo_train"],
+    ap.add_argument("--mode", default="render", choices=["render", "train", "kilo", "kilo_train", "testset"],
                     help="render: BASELINE configs[1] (default, the headline metric); train: configs[2], "
                          "4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce; kilo: configs[3], KiloNeRF "
-                         "800x800 frame with the sphere occupancy grid; kilo_train: KiloNeRF distillation step (SURVEY 8f rank 3)")
+                         "800x800 frame with the sphere occupancy grid; kilo_train: KiloNeRF distillation step (SURVEY 8f rank 3); testset: configs[4], the 200-view test set "
+                         "dealt round-robin over the ranks (strong scaling; a step = one pass over all views, a warm-up step = one "
+                         "view per rank; use with --dtype bf16)")
+    ap.add_argument("--views", type=int, default=200, help="testset mode: number of views in the set")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="render mode only: fp32 = BASELINE configs[1] (the headline metric); bf16 = the bf16 MLP of "
                          "configs[4], reported under its own metric name")
@@ -315,6 +318,71 @@ def kilo_train_bench(args, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def testset_bench(args, net, dev, rank, world, dist):
+    """BASELINE configs[4]: the 200 test views (theta = -180 ... 178.2 deg), (view) items dealt round-robin over the
+    ranks (nerf_amd.parallel.view_schedule), no data-path collective.  Strong scaling: the set is fixed."""
+    from nerf_amd import ops
+    from nerf_amd.camera import test_set_poses, focal_from_angle
+    from nerf_amd.config import default_cfg
+    from nerf_amd.parallel import view_schedule
+    from nerf_amd.renderer import Renderer
+    renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=args.dtype)
+    poses = test_set_poses(args.views)
+    focal = focal_from_angle(W)
+    R = H * W
+    mine = [v for v, _ in view_schedule(len(poses), rank, world)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99 + rank)
+
+    def render(view):
+        rays_o, rays_d = ops.raygen(poses[view], H, W, focal, dev)
+        u = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
+        u2 = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
+        return renderer.render_rays(rays_o, rays_d, u, u2)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for k in range(args.warmup):
+            out = render(mine[k % len(mine)])
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for view in mine:
+                out = render(view)
+        sync()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out["fine_rgb_map"]).all()
+    if rank == 0:
+        bf16 = args.dtype == "bf16"
+        flop = float(len(poses)) * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
+        peak = (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS) * world
+        achieved = flop * args.steps / elapsed / 1e12
+        print(json.dumps({
+            "metric": "rays/sec (%d-view test set, 800x800, 64 coarse + 128 fine samples/ray%s)" % (len(poses), ", bf16 MLP" if bf16 else ""),
+            "value": len(poses) * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps / len(poses),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
+            "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
+            "config": {"workload": "BASELINE configs[4]: %d-view test-set render, views dealt round-robin over %d rank(s), %s MLP"
+                                   % (len(poses), world, args.dtype), "views": len(poses), "rays_per_frame": R,
+                       "views_per_rank": len(mine)},
+            "roofline": {"kernel": "whole job (MLP FLOPs of all views / wall time / (peak x ranks))", "bound": "mfma",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}}),
+            flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -353,6 +421,8 @@ def main():
     net.to(dev)
     if args.mode == "train":
         return train_bench(args, net, dev, rank, world, dist)
+    if args.mode == "testset":
+        return testset_bench(args, net, dev, rank, world, dist)
     renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=args.dtype)
     bf16 = args.dtype == "bf16"
     peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
