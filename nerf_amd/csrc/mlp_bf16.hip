@@ -323,6 +323,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
                         }
             }
         }
+        // (Folding these dot products into the block epilogues of pts_linears.7 was measured: its layer body is shared
+        // with pts_linears.1 / .3, which then run the same 128 VALU instructions per block for nothing, and VALU work
+        // in the MFMAs' shadow is not free here -- 109.0 vs 106.5 ms per fine pass; a private copy of the body does
+        // not fit the instruction cache.)
         // Pin the alpha head HERE: LLVM otherwise sinks it to its use behind the views layer and keeps XB alive across
         // it in scratch -- and every scratch reload's vmcnt(0) also drains the LDS-DMA ring (measured: 42 % of the
         // kernel's wave time parked in s_waitcnt).
