@@ -298,3 +298,16 @@ def test_distillation_pipeline_reduces_loss(dev, tmp_path):
     b = ds.batch([0, 1])
     step.step(b["xyz"], b["viewdirs"], b["teacher_rgb"], None, stage="fine-tuning")
     assert np.isfinite(float(step.loss)) and step.t == 1
+
+
+def test_renderer_autograd_with_no_samples(dev):
+    """Empty occupancy grid: no ray produces a sample; the image is the background and every gradient is zero."""
+    from nerf_amd.kilonerf import KiloNetwork, KiloRenderer, default_kilo_cfg
+    net = KiloNetwork().to(dev)
+    r = KiloRenderer(net, default_kilo_cfg(), torch.zeros((256, 256, 256), dtype=torch.uint8, device=dev))
+    o, d = _rays(6)
+    out = r({"xyz": _t(o, dev)[None], "viewdirs": _t(d, dev)[None]}, is_training=True)
+    assert r.last_num_samples == 0 and torch.all(out["rgb_map"] == 1) and torch.all(out["alpha_map"] == 0)
+    (out["rgb_map"].sum() + out["alpha_map"].sum()).backward()
+    for p in net.model.tensors():
+        assert p.grad is not None and torch.all(p.grad == 0)
