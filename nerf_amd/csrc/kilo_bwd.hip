@@ -170,10 +170,12 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                                                           const int* __restrict__ perm, const float* __restrict__ pts,
                                                           const float* __restrict__ dirs, const int* __restrict__ dir_index,
                                                           const float4* __restrict__ grad_raw, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float s_tile[4][kTileRows * kTileStride];
+    // dynamic LDS: [4 waves][tile] then [4 waves][the job's cell record: forward operands, biases, head rows]
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
-    float* T = s_tile[threadIdx.x >> 6];
+    float* T = s_dyn + (threadIdx.x >> 6) * (kTileRows * kTileStride);
+    float* Wl = s_dyn + 4 * (kTileRows * kTileStride) + (threadIdx.x >> 6) * kKiloCellFloats;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n_waves = gridDim.x * 4;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -196,21 +198,45 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
         float dsb = 0.f, drb[3] = {0.f, 0.f, 0.f};
         {
             const float* cw = packed + int64_t(cell) * kKiloCellFloats;
-            const float4* w4_cell = reinterpret_cast<const float4*>(cw) + lane;
+            // Stage the cell's forward record in this wave's LDS slice once per job: all its loads are in flight
+            // together, and the tile loop then reads operands at LDS latency instead of L2 latency per layer.
+            {
+                wave_sync();   // the previous job's reads of this slice are done (same wave, in order)
+#pragma unroll
+                for (int g8 = 0; g8 < kKiloSteps; g8 += 8) {   // 8 float4 at a time: the register file is full of accumulators
+                    float4 stage[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) stage[s] = reinterpret_cast<const float4*>(cw)[(g8 + s) * 64 + lane];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) reinterpret_cast<float4*>(Wl)[(g8 + s) * 64 + lane] = stage[s];
+                }
+                const float4 tail0 = reinterpret_cast<const float4*>(cw)[kKiloSteps * 64 + lane];
+                const float4 tail1 = reinterpret_cast<const float4*>(cw)[kKiloSteps * 64 + 64 + (lane & 7)];
+                reinterpret_cast<float4*>(Wl)[kKiloSteps * 64 + lane] = tail0;
+                if (lane < 8) reinterpret_cast<float4*>(Wl)[kKiloSteps * 64 + 64 + lane] = tail1;
+                wave_sync();
+            }
+            const float4* w4_cell = reinterpret_cast<const float4*>(Wl) + lane;
             const float4* wt4_cell = reinterpret_cast<const float4*>(packed_t + int64_t(cell) * kKiloCellTFloats) + lane;
-            const float* sm_cell = cw + kKiloSteps * 256;
+            const float* sm_cell = Wl + kKiloSteps * 256;
             const int last = job_e - 1;
+            // Gather pipeline: perm -> (point, dir index, d raw) -> direction is three dependent loads; the next tile's
+            // chain is issued piecewise between the phases of this tile (reads past the job's last tile are clamped to
+            // its last element: valid memory, results unused).
+            auto tile_id = [&](int t) { const int k = t + j; return unsigned(perm[k < last ? k : last]); };
+            unsigned id_n = tile_id(first);
+            unsigned di_n = INDEXED ? unsigned(dir_index[id_n]) : id_n;
+            float pn[3] = {pts[id_n * 3u], pts[id_n * 3u + 1], pts[id_n * 3u + 2]};
+            float4 gr_n = grad_raw[id_n];
+            float dn[3] = {dirs[di_n * 3u], dirs[di_n * 3u + 1], dirs[di_n * 3u + 2]};
             for (int t0 = first; t0 < job_e; t0 += 32) {
                 const bool valid = t0 + j < job_e;
-                const int k = t0 + j < last ? t0 + j : last;
-                const unsigned id = unsigned(perm[k]);
-                const unsigned di = INDEXED ? unsigned(dir_index[id]) : id;
-                const float px = pts[id * 3u], py = pts[id * 3u + 1], pz = pts[id * 3u + 2];
-                const float dx = dirs[di * 3u], dy = dirs[di * 3u + 1], dz = dirs[di * 3u + 2];
-                float4 gr = grad_raw[id];
+                const float px = pn[0], py = pn[1], pz = pn[2], dx = dn[0], dy = dn[1], dz = dn[2];
+                float4 gr = gr_n;
                 if (!valid) gr = make_float4(0.f, 0.f, 0.f, 0.f);   // tail lanes repeat the last point: no gradient
+                id_n = tile_id(t0 + 32);                            // next tile, stage 1
                 // The cell's record is loop-invariant, and hoisting its 60 float4 out of the tile loop is exactly what the
-                // register file cannot take: launder the offset so every tile re-reads it (L1/L2 hits).
+                // register file cannot take: launder the offset so every tile re-reads it (LDS; L2 for the transposed part).
                 int again = 0;
                 asm volatile("" : "+v"(again));
                 const float4* w4 = w4_cell + again;
@@ -233,6 +259,11 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                 x[0] = tiny_layer_g<1>(w4 + 12 * 64, bias(2), &h1);                    // feature, no activation
                 x[1] = encode_block<4, 0>(dx, dy, dz, h);
                 const f32x16 hv = relu16(tiny_layer_g<2>(w4 + 16 * 64, bias(3), x));
+
+                // next tile, stage 2 (its index arrived during the forward chain)
+                di_n = INDEXED ? unsigned(dir_index[id_n]) : id_n;
+                pn[0] = pts[id_n * 3u], pn[1] = pts[id_n * 3u + 1], pn[2] = pts[id_n * 3u + 2];
+                gr_n = grad_raw[id_n];
 
                 // ---- data gradients ----
                 const f32x16 sw = *reinterpret_cast<const f32x16*>(sm + kKOffSigW + h * 16);
@@ -262,6 +293,10 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
 #pragma unroll
                 for (int t = 0; t < 16; ++t) d_h0[t] = h0[t] > 0.f ? d_h0[t] : 0.f;
 
+                // next tile, stage 3
+                dn[0] = dirs[di_n * 3u], dn[1] = dirs[di_n * 3u + 1], dn[2] = dirs[di_n * 3u + 2];
+
+#ifndef KB_ABL_NOWGRAD  // timing-only ablation builds (tools/debug/kilo_bwd_time.py): results are wrong
                 // ---- weight gradients: turn both operands through the LDS tile, one layer at a time ----
                 tile_store(T, kRowDy, d_h0, j, h);                 // layer 0: X = encoding (+ ones), rows 0..63
                 wave_sync();
@@ -289,6 +324,7 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                 dWv[0] = wgrad_block(T, kRowDy, 0, dWv[0], j, h);
                 dWv[1] = wgrad_block(T, kRowDy, 32, dWv[1], j, h);
                 wave_sync();
+#endif
             }
         }
 
@@ -471,6 +507,9 @@ NRF_EXPORT int nrf_kilo_pack_weights_transposed(const float* const* tensors, int
 // tiles per job: 4 (128 points) unless that would make more than ~8192 + num_cells jobs
 static int bwd_tiles_per_job(int64_t n_points) {
     const int64_t t = (n_points + 32 * 8192 - 1) / (32 * 8192);
+#ifdef KB_ABL_TPJ
+    return int(t < KB_ABL_TPJ ? KB_ABL_TPJ : t);
+#endif
     return int(t < 4 ? 4 : t);
 }
 
@@ -510,17 +549,24 @@ NRF_EXPORT int nrf_kilo_backward(const float* packed, const float* packed_t, int
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
+    constexpr int kBwdLds = 4 * (kTileRows * kTileStride + kKiloCellFloats) * 4;   // 158,208 B of the CU's 160 KiB
+    static_assert(kKiloSmall == 288 && kBwdLds <= 160 * 1024, "LDS budget / staging of the 72 float4 behind the operands");
     nrf_launch_begin();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&kilo_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kBwdLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&kilo_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kBwdLds) != hipSuccess)
+        return NRF_ERR_LAUNCH;
     if (n_points == 0) {  // no forward ran: every segment is empty
         (void)hipMemsetAsync(job_prefix, 0, size_t(num_cells + 1) * 4, stream);
     } else {
         kilo_job_scan_kernel<<<1, 1024, 0, stream>>>(ws.seg_start, num_cells, tpj, job_prefix);
         if (dir_index)
-            kilo_bwd_kernel<true><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, packed_t, num_cells, ws.seg_start, job_prefix,
+            kilo_bwd_kernel<true><<<dim3(unsigned(cus)), 256, kBwdLds, stream>>>(packed, packed_t, num_cells, ws.seg_start, job_prefix,
                                                                            tpj, ws.perm, pts, dirs, dir_index,
                                                                            reinterpret_cast<const float4*>(grad_raw), partial);
         else
-            kilo_bwd_kernel<false><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, packed_t, num_cells, ws.seg_start, job_prefix,
+            kilo_bwd_kernel<false><<<dim3(unsigned(cus)), 256, kBwdLds, stream>>>(packed, packed_t, num_cells, ws.seg_start, job_prefix,
                                                                             tpj, ws.perm, pts, dirs, dir_index,
                                                                             reinterpret_cast<const float4*>(grad_raw), partial);
     }
