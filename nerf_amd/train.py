@@ -20,6 +20,14 @@ from .parallel import allreduce_gradients
 from .renderer import near_far_table
 
 
+def exponential_lr(base_lr: float, epoch: int, decay_epochs: int = 500, gamma: float = 0.1) -> float:
+    """The reference's per-epoch schedule (src/utils/optimizer/lr_scheduler.py:75-79 with configs/nerf/lego.yaml:83-90:
+    ``base_lr * gamma ** (epoch / decay_epochs)``; KiloNeRF: gamma 0.9 / 100 epochs while distilling, 0.1 / 500 while
+    fine-tuning, configs/kilonerf/lego.yaml:124-133).  Assign the result to ``TrainStep.lr`` / ``KiloTrainStep.lr``
+    once per epoch, as ``scheduler.step()`` does (train.py / train_kilonerf.py:96)."""
+    return base_lr * gamma ** (epoch / decay_epochs)
+
+
 class TrainStep:
     def __init__(self, net, device, near=2.0, far=6.0, n_coarse=64, n_importance=128, white_bkgd=True,
                  lr=5e-4, clip_value=40.0, process_group=None):

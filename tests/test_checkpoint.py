@@ -74,3 +74,19 @@ def test_psnr_and_evaluator():
     ev.evaluate({"rgb_map": torch.from_numpy(pred)[None]}, batch)    # KiloNeRF's output dict (evaluators/kilonerf.py:55)
     s = ev.summarize()
     assert abs(s["mean_psnr"] - want) < 1e-5 and ev.summarize() == {}
+
+
+def test_exponential_lr_matches_torch_scheduler_formula():
+    """lr_scheduler.py:75-79 restated on a real torch optimiser: lr_e = base * gamma ** (e / decay_epochs)."""
+    from nerf_amd.train import exponential_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=5e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 0.1 ** (e / 500))
+    for epoch in range(0, 1200, 97):
+        want = 5e-4 * 0.1 ** (epoch / 500)
+        assert abs(exponential_lr(5e-4, epoch) - want) < 1e-15
+    for epoch in range(3):
+        assert abs(opt.param_groups[0]["lr"] - exponential_lr(5e-4, epoch)) < 1e-12
+        opt.step()
+        sched.step()
+    assert abs(exponential_lr(5e-4, 100, 100, 0.9) - 4.5e-4) < 1e-12
