@@ -29,13 +29,14 @@ class KiloTrainStep:
     def __init__(self, renderer, device, lr=5e-4, clip_value=40.0, l2_reg=1e-6, process_group=None):
         self.renderer = renderer
         self.net = renderer.net
+        self.view = renderer.view
         self.device = torch.device(device)
         self.lr, self.clip, self.l2_reg = lr, clip_value, l2_reg
         self.group = process_group
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
-        params = self.net.model.tensors()
+        params = self.view.tensors()
         sizes = [p.numel() for p in params]
         self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
         self.grad = torch.empty_like(self.flat)
@@ -64,7 +65,7 @@ class KiloTrainStep:
 
     def forward_backward(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation"):
         """Fills self.grad (all 12 tensors, flat) and self.loss; returns the render outputs."""
-        r, net = self.renderer, self.net
+        r, net = self.renderer, self.view
         o, d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
         aabb, res = net.grid()
         if r.occ_grid.device != o.device:
@@ -96,5 +97,5 @@ class KiloTrainStep:
         self.t += 1
         ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.t, lr=self.lr, clip_value=self.clip,
                       grad_scale=scale)
-        self.net._packed_key = None   # the in-place update does not bump tensor versions: drop the inference pack
+        self.view.invalidate()        # the in-place update does not bump tensor versions: drop the inference pack
         return out

@@ -117,6 +117,57 @@ class KiloNetwork(nn.Module):
                 torch.sum(m.rgb_linear_weights ** 2) + torch.sum(m.rgb_linear_biases ** 2))
 
 
+class KiloNetView:
+    """What the renderer needs from a KiloNeRF network, for ``KiloNetwork`` and equally for the reference's own
+    ``src.models.kilonerf.network.Network`` (same parameter names ``model.pts_linears_weights.0`` ... and buffers
+    ``aabb_min`` / ``aabb_max`` / ``grid_resolution``, network.py:172-220): the 12 tensors in C-ABI order, the grid,
+    and a packed copy that is rebuilt when a parameter's version changes."""
+
+    def __init__(self, net: nn.Module):
+        self.net = net
+        self._packed = None
+        self._packed_key = None
+        self._grid = None
+
+    def tensors(self):
+        model = getattr(self.net, "model", None)
+        if hasattr(model, "tensors"):
+            return model.tensors()
+        named = dict(self.net.named_parameters())
+        try:
+            return [named["model." + n] for n, _, _ in KILO_TENSORS]
+        except KeyError as e:
+            raise kilo_ops.NrfError(f"network has no parameter {e}: expected the reference's BatchedKiloNeRF layout") from e
+
+    @property
+    def num_models(self) -> int:
+        return int(self.tensors()[0].shape[0])
+
+    def grid(self):
+        if hasattr(self.net, "grid"):
+            return self.net.grid()
+        if self._grid is None:
+            aabb = [float(v) for v in self.net.aabb_min.tolist()] + [float(v) for v in self.net.aabb_max.tolist()]
+            self._grid = (aabb, [int(v) for v in self.net.grid_resolution.tolist()])
+        return self._grid
+
+    def packed(self) -> torch.Tensor:
+        if hasattr(self.net, "packed"):
+            return self.net.packed()
+        ts = self.tensors()
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if self._packed is None or key != self._packed_key or self._packed.device != ts[0].device:
+            same_dev = self._packed is not None and self._packed.device == ts[0].device
+            self._packed = kilo_ops.kilo_pack_weights(ts, self._packed if same_dev else None)
+            self._packed_key = key
+        return self._packed
+
+    def invalidate(self):
+        self._packed_key = None
+        if hasattr(self.net, "_packed_key"):
+            self.net._packed_key = None
+
+
 def _ref_layer_params(model):
     """Weights / biases of a reference-style NeRF module in include/nerf_amd.h order."""
     from .ops import LAYER_NAMES
@@ -130,7 +181,7 @@ class _KiloRenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, renderer, o, d, *params):
-        net = renderer.net
+        net = renderer.view
         aabb, res = net.grid()
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, renderer.occ_grid, aabb, renderer.near,
                                                                     renderer.far, renderer.step)
@@ -150,7 +201,7 @@ class _KiloRenderFn(torch.autograd.Function):
         g_raw = kilo_ops.kilo_composite_backward(raw, ts, te, offsets, counts, r.ert, r.white_bkgd, g_rgb.contiguous(),
                                                  g_depth.contiguous(), g_acc.contiguous())
         packed_t = kilo_ops.kilo_pack_weights_transposed(ctx.params)
-        grads = kilo_ops.kilo_backward(packed, packed_t, r.net.num_models, pts, d, ray_idx, g_raw, ws)
+        grads = kilo_ops.kilo_backward(packed, packed_t, r.view.num_models, pts, d, ray_idx, g_raw, ws)
         return (None, None, None) + tuple(grads)
 
 
@@ -161,7 +212,14 @@ class KiloRenderer(nn.Module):
     def __init__(self, net: KiloNetwork, cfg=None, occ_grid: torch.Tensor | None = None):
         super().__init__()
         self.net = net
-        cfg = cfg or default_kilo_cfg()
+        self.view = KiloNetView(net)
+        ref_cfg = None
+        if cfg is None:
+            try:  # inside the reference tree: its global config (volumn_renderer.py:5)
+                from src.config import cfg as ref_cfg  # type: ignore
+                cfg = ref_cfg
+            except Exception:
+                cfg = default_kilo_cfg()
         s = cfg.sampler
         self.near, self.far = float(s.near), float(s.far)
         self.step, self.ert = float(s.render_step_size), float(s.ert_threshold)
@@ -171,6 +229,25 @@ class KiloRenderer(nn.Module):
         self.last_num_samples = 0
         if occ_grid is not None:
             self.set_occ_grid(occ_grid)
+        elif ref_cfg is not None:
+            self._init_grid_from_reference_cfg(ref_cfg)
+
+    def _init_grid_from_reference_cfg(self, cfg):
+        """volumn_renderer.py:36-44: load ``<result_dir>/occ_grid_res{X}_{Y}_{Z}_thresh{t}.pth`` if it exists, else bake
+        it from the teacher checkpoint (``cfg.teacher_model_dir``, :149-150) and save it."""
+        import os
+        from .checkpoint import load_network, resolve_checkpoint
+        self.grid_path = os.path.join(cfg.result_dir, self.grid_filename(cfg.sampler.occ_threshold))
+        dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        if os.path.exists(self.grid_path):
+            self.load_occ_grid(self.grid_path, dev)
+        elif getattr(cfg, "teacher_model_dir", None) and resolve_checkpoint(cfg.teacher_model_dir):
+            from .network import Network
+            teacher = Network()
+            load_network(teacher, cfg.teacher_model_dir)
+            self.bake_occ_grid(teacher.to(dev), float(cfg.sampler.occ_threshold))
+            os.makedirs(cfg.result_dir, exist_ok=True)
+            self.save_occ_grid(self.grid_path)
 
     def set_occ_grid(self, occ_grid: torch.Tensor):
         if list(occ_grid.shape) != list(self.occ_grid_resolution):
@@ -189,7 +266,7 @@ class KiloRenderer(nn.Module):
         ws, bs = teacher.model_fine.layer_params() if hasattr(teacher.model_fine, "layer_params") else _ref_layer_params(
             teacher.model_fine)
         packed = ops.pack_weights(ws, bs)
-        aabb, _ = self.net.grid()
+        aabb, _ = self.view.grid()
         self.set_occ_grid(kilo_ops.occ_bake(packed, aabb, self.occ_grid_resolution, occ_threshold, chunk_cells))
         return self.occ_grid
 
@@ -207,7 +284,7 @@ class KiloRenderer(nn.Module):
         o, d = rays_o.reshape(-1, 3).contiguous(), viewdirs.reshape(-1, 3).contiguous()
         if self.occ_grid.device != o.device:
             self.occ_grid = self.occ_grid.to(o.device)
-        params = self.net.model.tensors()
+        params = self.view.tensors()
         if is_training and torch.is_grad_enabled() and any(p.requires_grad for p in params):
             rgb, depth, acc = _KiloRenderFn.apply(self, o, d, *params)
         else:
@@ -216,12 +293,12 @@ class KiloRenderer(nn.Module):
         return {"rgb_map": rgb.view(B, R, 3), "depth_map": depth.view(B, R, 1), "alpha_map": acc.view(B, R, 1)}
 
     def _render(self, o, d):
-        aabb, res = self.net.grid()
+        aabb, res = self.view.grid()
         occ = self.occ_grid
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, occ, aabb, self.near, self.far, self.step)
         self.last_num_samples = int(pts.shape[0])
         if pts.shape[0]:
-            raw = kilo_ops.kilo_forward(self.net.packed(), self.net.num_models, aabb, res, pts, d, ray_idx)
+            raw = kilo_ops.kilo_forward(self.view.packed(), self.view.num_models, aabb, res, pts, d, ray_idx)
         else:
             raw = torch.empty((0, 4), dtype=torch.float32, device=o.device)
         return kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.ert, self.white_bkgd)

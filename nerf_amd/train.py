@@ -44,7 +44,12 @@ class TrainStep:
         self.models = []
         for k, name in enumerate(("model", "model_fine")):
             model = getattr(net, name)
-            ws, bs = model.layer_params()
+            if hasattr(model, "layer_params"):
+                ws, bs = model.layer_params()
+            else:   # the reference's own NeRF module: same layer names (network.py:10-47)
+                named = dict(model.named_parameters())
+                ws = [named[n + ".weight"] for n in ops.LAYER_NAMES]
+                bs = [named[n + ".bias"] for n in ops.LAYER_NAMES]
             views = ops.split_flat_grad(self.flat[k * n:(k + 1) * n])
             for (w, b), (vw, vb) in zip(zip(ws, bs), views):
                 vw.copy_(w.detach())
