@@ -195,7 +195,7 @@ def test_kilo_renderer_vs_oracle(dev):
     assert rgb.shape == (6, 5, 3) and sigma.shape == (6, 5, 1)
     ref_raw = K.network_forward(sd, p.cpu(), torch.from_numpy(d[:6]), AABB[:3], AABB[3:], RES).numpy()
     assert np.abs(torch.cat([rgb, sigma], -1).reshape(-1, 4).cpu().numpy() - ref_raw).max() < 1e-3
-    assert abs(float(net.get_color_reg_loss()) - K.color_reg_loss(sd)) < 1e-3 * K.color_reg_loss(sd)
+    assert abs(float(net.get_color_reg_loss().detach()) - K.color_reg_loss(sd)) < 1e-3 * K.color_reg_loss(sd)
 
 
 def test_occupancy_bake_vs_oracle(dev):
@@ -243,3 +243,31 @@ def test_bake_points_match_torch_formula(dev):
             assert np.array_equal(pts, ref)
         else:
             assert np.abs(pts - ref).max() <= 2.5e-7 * 3.3
+
+
+def test_renderer_with_reference_style_network_module(dev):
+    """KiloRenderer on a module that only has the reference's parameter / buffer names (what the drop-in sees when
+    the reference keeps its own src.models.kilonerf.network.Network): same bits as with KiloNetwork, and a
+    parameter update is picked up (version-keyed repack)."""
+    from test_dropin import _RefStyleKiloNet
+    from nerf_amd.kilonerf import KiloNetwork, KiloRenderer, default_kilo_cfg
+    sd = _sd(3, 10.0, 0.5)
+    a = KiloNetwork()
+    a.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    b = _RefStyleKiloNet(4096)
+    b.grid_resolution.copy_(torch.tensor([16, 16, 16]))
+    missing = b.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not missing.unexpected_keys and set(missing.missing_keys) <= {"aabb_min", "aabb_max", "grid_resolution"}
+    occ = _t(_sphere_occ(256), dev)
+    ra, rb = KiloRenderer(a.to(dev), default_kilo_cfg(), occ), KiloRenderer(b.to(dev), default_kilo_cfg(), occ)
+    o = torch.tensor([[0.0, 0.0, 4.0]], device=dev).repeat(64, 1) + 0.01 * torch.randn(64, 3, device=dev)
+    d = torch.tensor([[0.0, 0.0, -1.0]], device=dev).repeat(64, 1) + 0.05 * torch.randn(64, 3, device=dev)
+    batch = {"xyz": o[None], "viewdirs": d[None]}
+    oa, ob = ra(batch, is_training=False), rb(batch, is_training=False)
+    assert ra.last_num_samples == rb.last_num_samples > 1000
+    for k in ("rgb_map", "depth_map", "alpha_map"):
+        assert torch.equal(oa[k], ob[k]), k
+    with torch.no_grad():
+        b.model.rgb_linear_biases.add_(0.5)
+    oc = rb(batch, is_training=False)
+    assert not torch.equal(oc["rgb_map"], ob["rgb_map"])
