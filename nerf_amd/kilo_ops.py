@@ -99,6 +99,11 @@ def kilo_backward(packed, packed_t, num_cells: int, pts, dirs, dir_index, grad_r
     grad_raw = _f32(grad_raw, "grad_raw").reshape(-1, 4)
     if grad_raw.shape[0] != n:
         raise NrfError(f"grad_raw has {grad_raw.shape[0]} rows for {n} points")
+    if dir_index is None:
+        if dirs.shape[0] != n:
+            raise NrfError(f"dirs has {dirs.shape[0]} rows for {n} points and no dir_index")
+    elif dir_index.dtype != torch.int32 or dir_index.numel() != n or not dir_index.is_cuda or not dir_index.is_contiguous():
+        raise NrfError("dir_index: expected a contiguous int32 cuda tensor with one entry per point")
     dev = packed.device
     if grads is None:
         grads = [torch.empty((num_cells,) + shape, dtype=torch.float32, device=dev) for _, shape, _ in KILO_TENSORS]

@@ -22,6 +22,10 @@ from . import kilo_ops, ops
 from .parallel import allreduce_gradients
 from .weights import KILO_TENSORS
 
+def r_occ_missing(renderer) -> bool:
+    return renderer.occ_grid is None
+
+
 _REG_TENSORS = ("view_linears_weights", "view_linears_biases", "rgb_linear_weights", "rgb_linear_biases")
 
 
@@ -65,6 +69,12 @@ class KiloTrainStep:
 
     def forward_backward(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation"):
         """Fills self.grad (all 12 tensors, flat) and self.loss; returns the render outputs."""
+        if stage not in ("distillation", "fine-tuning"):
+            raise ValueError(f"stage {stage!r}: expected 'distillation' or 'fine-tuning' (train_kilonerf.py:74-78)")
+        if stage == "distillation" and target_alpha is None:
+            raise ValueError("the distillation stage needs teacher_alpha (trainers/kilonerf.py:44-47)")
+        if r_occ_missing(self.renderer):
+            raise RuntimeError("KiloRenderer: no occupancy grid (set_occ_grid)")
         r, net = self.renderer, self.view
         o, d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
         aabb, res = net.grid()
