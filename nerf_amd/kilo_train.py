@@ -22,10 +22,6 @@ from . import kilo_ops, ops
 from .parallel import allreduce_gradients
 from .weights import KILO_TENSORS
 
-def r_occ_missing(renderer) -> bool:
-    return renderer.occ_grid is None
-
-
 _REG_TENSORS = ("view_linears_weights", "view_linears_biases", "rgb_linear_weights", "rgb_linear_biases")
 
 
@@ -73,7 +69,7 @@ class KiloTrainStep:
             raise ValueError(f"stage {stage!r}: expected 'distillation' or 'fine-tuning' (train_kilonerf.py:74-78)")
         if stage == "distillation" and target_alpha is None:
             raise ValueError("the distillation stage needs teacher_alpha (trainers/kilonerf.py:44-47)")
-        if r_occ_missing(self.renderer):
+        if self.renderer.occ_grid is None:
             raise RuntimeError("KiloRenderer: no occupancy grid (set_occ_grid)")
         r, net = self.renderer, self.view
         o, d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
