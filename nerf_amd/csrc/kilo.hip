@@ -21,48 +21,50 @@
 
 namespace {
 
-__global__ void kilo_pack_kernel(KiloSrc s, int num_cells, float* __restrict__ packed) {
-    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= int64_t(num_cells) * kKiloCellFloats) return;
-    const int cell = int(gid / kKiloCellFloats), idx = int(gid - int64_t(cell) * kKiloCellFloats);
-    float v = 0.f;
-    if (idx < kKiloSteps * 256) {
-        const int e = idx & 3, lane = (idx >> 2) & 63, step = idx >> 8;
-        const int h = lane >> 5, row = lane & 31, q = step & 3, t = 4 * q + e;
-        if (step < 8) {  // pts0: 63 encoding columns, kernel slot order
-            const int c = pe_col((step >> 2) * 16 + t, h, 10);
-            if (c >= 0) v = s.t[0][(int64_t(cell) * 32 + row) * 63 + c];
-        } else if (step < 12) {
-            v = s.t[2][(int64_t(cell) * 32 + row) * 32 + acc_row(t, h)];
-        } else if (step < 16) {
-            v = s.t[4][(int64_t(cell) * 32 + row) * 32 + acc_row(t, h)];
-        } else if (step < 20) {  // view layer, feature columns 0..31
-            v = s.t[8][(int64_t(cell) * 32 + row) * 59 + acc_row(t, h)];
-        } else {  // view layer, direction encoding columns 32..58
-            const int c = pe_col(t, h, 4);
-            if (c >= 0) v = s.t[8][(int64_t(cell) * 32 + row) * 59 + 32 + c];
+__global__ __launch_bounds__(256) void kilo_pack_kernel(KiloSrc s, int num_cells, float* __restrict__ packed) {
+    __shared__ float rec[kRecFloats];
+    const int cell = blockIdx.x;
+    stage_cell_record(s, cell, rec);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kKiloCellFloats; idx += 256) {
+        float v = 0.f;
+        if (idx < kKiloSteps * 256) {
+            const int e = idx & 3, lane = (idx >> 2) & 63, step = idx >> 8;
+            const int h = lane >> 5, row = lane & 31, q = step & 3, t = 4 * q + e;
+            if (step < 8) {  // pts0: 63 encoding columns, kernel slot order
+                const int c = pe_col((step >> 2) * 16 + t, h, 10);
+                if (c >= 0) v = rec[REC_OFF(0) + row * 63 + c];
+            } else if (step < 12) {
+                v = rec[REC_OFF(2) + row * 32 + acc_row(t, h)];
+            } else if (step < 16) {
+                v = rec[REC_OFF(4) + row * 32 + acc_row(t, h)];
+            } else if (step < 20) {  // view layer, feature columns 0..31
+                v = rec[REC_OFF(8) + row * 59 + acc_row(t, h)];
+            } else {  // view layer, direction encoding columns 32..58
+                const int c = pe_col(t, h, 4);
+                if (c >= 0) v = rec[REC_OFF(8) + row * 59 + 32 + c];
+            }
+        } else {
+            const int i = idx - kKiloSteps * 256;
+            if (i < 128) {
+                const int layer = i >> 5, h = (i >> 4) & 1, r = i & 15;
+                const int off = layer == 0 ? REC_OFF(1) : layer == 1 ? REC_OFF(3) : layer == 2 ? REC_OFF(5) : REC_OFF(9);
+                v = rec[off + acc_row(r, h)];
+            } else if (i < 160) {
+                const int h = ((i - 128) >> 4) & 1, r = i & 15;
+                v = rec[REC_OFF(6) + acc_row(r, h)];
+            } else if (i < 256) {
+                const int j = i - 160, c = j >> 5, h = (j >> 4) & 1, r = j & 15;
+                v = rec[REC_OFF(10) + c * 32 + acc_row(r, h)];
+            } else if (i == kKOffSigB) {
+                v = rec[REC_OFF(7)];
+            } else if (i < kKOffRgbB + 3) {
+                v = rec[REC_OFF(11) + (i - kKOffRgbB)];
+            }
         }
-    } else {
-        const int i = idx - kKiloSteps * 256;
-        if (i < 128) {
-            const int layer = i >> 5, h = (i >> 4) & 1, r = i & 15;
-            const int src = layer == 0 ? 1 : layer == 1 ? 3 : layer == 2 ? 5 : 9;
-            v = s.t[src][int64_t(cell) * 32 + acc_row(r, h)];
-        } else if (i < 160) {
-            const int h = ((i - 128) >> 4) & 1, r = i & 15;
-            v = s.t[6][int64_t(cell) * 32 + acc_row(r, h)];
-        } else if (i < 256) {
-            const int j = i - 160, c = j >> 5, h = (j >> 4) & 1, r = j & 15;
-            v = s.t[10][(int64_t(cell) * 3 + c) * 32 + acc_row(r, h)];
-        } else if (i == kKOffSigB) {
-            v = s.t[7][cell];
-        } else if (i < kKOffRgbB + 3) {
-            v = s.t[11][int64_t(cell) * 3 + (i - kKOffRgbB)];
-        }
+        packed[int64_t(cell) * kKiloCellFloats + idx] = v;
     }
-    packed[gid] = v;
 }
-
 
 // kilonerf/network.py:322-334, op for op in fp32: (p - min) / (max - min) * res, clamp(min=0),
 // min(res - 1), truncate.  Bit-exact (IEEE subtract / divide / multiply, no contraction).
@@ -440,9 +442,8 @@ NRF_EXPORT int nrf_kilo_pack_weights(const float* const* tensors, int num_cells,
         s.t[i] = tensors[i];
     }
     if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
-    const int64_t total = int64_t(num_cells) * kKiloCellFloats;
     nrf_launch_begin();
-    kilo_pack_kernel<<<dim3(unsigned((total + 255) / 256)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, packed);
+    kilo_pack_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, packed);
     return nrf_launch_status();
 }
 

@@ -34,13 +34,7 @@ struct KiloGrad {
     float* t[12];  // KILO tensor order, reference layouts
 };
 
-// One job's partial gradients: the 12 tensors' per-cell slices back to back (6212 floats).
-constexpr int kRecOff[13] = {0, 2016, 2048, 3072, 3104, 4128, 4160, 4192, 4193, 6081, 6113, 6209, 6212};
-#define REC_OFF(t) (kRecOff[t])   // only ever indexed with literals: folds at compile time, no device-side array
-constexpr int kRecFloats = kRecOff[12];
-static_assert(kRecOff[1] == 32 * 63 && kRecOff[3] - kRecOff[2] == 32 * 32 && kRecOff[9] - kRecOff[8] == 32 * 59 &&
-                  kRecOff[11] - kRecOff[10] == 96,
-              "record layout = the 12 tensors' per-cell slices");
+// One job's partial gradients: the 12 tensors' per-cell slices back to back (kRecOff, kilo_common.h).
 constexpr int kRecStride = 6224;                          // 64-byte multiple
 static_assert(kRecFloats == 6212, "per-cell parameter count");
 
@@ -93,18 +87,21 @@ __global__ __launch_bounds__(256) void kilo_grad_reduce_kernel(const float* __re
 
 // A operands of the transposed chain: lane (row = input feature, half h), MFMA t contracts over output feature
 // acc_row(t, h) -- the order in which the accumulator layout presents dY^T as the B operand.
-__global__ void kilo_pack_t_kernel(KiloSrc s, int num_cells, float* __restrict__ packed_t) {
-    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= int64_t(num_cells) * kKiloCellTFloats) return;
-    const int cell = int(gid / kKiloCellTFloats), idx = int(gid - int64_t(cell) * kKiloCellTFloats);
-    const int e = idx & 3, lane = (idx >> 2) & 63, step = idx >> 8;
-    const int h = lane >> 5, row = lane & 31, t = 4 * (step & 3) + e;
-    const int k = acc_row(t, h);
-    float v;
-    if (step < 4) v = s.t[2][(int64_t(cell) * 32 + k) * 32 + row];        // pts_linears 1
-    else if (step < 8) v = s.t[4][(int64_t(cell) * 32 + k) * 32 + row];   // feature_linear
-    else v = s.t[8][(int64_t(cell) * 32 + k) * 59 + row];                 // view_linears, feature columns
-    packed_t[gid] = v;
+__global__ __launch_bounds__(256) void kilo_pack_t_kernel(KiloSrc s, int num_cells, float* __restrict__ packed_t) {
+    __shared__ float rec[kRecFloats];
+    const int cell = blockIdx.x;
+    stage_cell_record<false>(s, cell, rec);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kKiloCellTFloats; idx += 256) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, step = idx >> 8;
+        const int h = lane >> 5, row = lane & 31, t = 4 * (step & 3) + e;
+        const int k = acc_row(t, h);
+        float v;
+        if (step < 4) v = rec[REC_OFF(2) + k * 32 + row];        // pts_linears 1
+        else if (step < 8) v = rec[REC_OFF(4) + k * 32 + row];   // feature_linear
+        else v = rec[REC_OFF(8) + k * 59 + row];                 // view_linears, feature columns
+        packed_t[int64_t(cell) * kKiloCellTFloats + idx] = v;
+    }
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -497,10 +494,8 @@ NRF_EXPORT int nrf_kilo_pack_weights_transposed(const float* const* tensors, int
         s.t[i] = tensors[i];
     }
     if (!nrf_aligned16(packed_t)) return NRF_ERR_ALIGN;
-    const int64_t total = int64_t(num_cells) * kKiloCellTFloats;
     nrf_launch_begin();
-    kilo_pack_t_kernel<<<dim3(unsigned((total + 255) / 256)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells,
-                                                                                                         packed_t);
+    kilo_pack_t_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, packed_t);
     return nrf_launch_status();
 }
 

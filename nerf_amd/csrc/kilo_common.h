@@ -17,6 +17,28 @@ struct KiloSrc {
     const float* t[12];  // KILO tensor order: w0 b0 w1 b1 wf bf ws bs wv bv wr br, each (cells, ...)
 };
 
+// A cell's parameters as one record: the 12 tensors' per-cell slices back to back (6212 floats).
+constexpr int kRecOff[13] = {0, 2016, 2048, 3072, 3104, 4128, 4160, 4192, 4193, 6081, 6113, 6209, 6212};
+#define REC_OFF(t) (kRecOff[t])   // only ever indexed with literals: folds at compile time, no device-side array
+constexpr int kRecFloats = kRecOff[12];
+static_assert(kRecOff[1] == 32 * 63 && kRecOff[3] - kRecOff[2] == 32 * 32 && kRecOff[9] - kRecOff[8] == 32 * 59 &&
+                  kRecOff[11] - kRecOff[10] == 96,
+              "record layout = the 12 tensors' per-cell slices");
+
+// Coalesced copy of one cell's slices of the 12 (cells, ...) tensors into LDS (block of 256 threads); the packers
+// then permute out of LDS instead of gathering 4-byte elements from twelve places in HBM.
+template <bool ALL = true>   // ALL = false: only the three matrices the transposed packer reads
+__device__ __forceinline__ void stage_cell_record(const KiloSrc& s, int cell, float* rec) {
+#define STAGE(K)                                                                                        \
+    for (int i = threadIdx.x; i < REC_OFF(K + 1) - REC_OFF(K); i += 256)                                \
+        rec[REC_OFF(K) + i] = s.t[K][int64_t(cell) * (REC_OFF(K + 1) - REC_OFF(K)) + i];
+    STAGE(2) STAGE(4) STAGE(8)
+    if (ALL) {
+        STAGE(0) STAGE(1) STAGE(3) STAGE(5) STAGE(6) STAGE(7) STAGE(9) STAGE(10) STAGE(11)
+    }
+#undef STAGE
+}
+
 struct Grid {
     float mn[3], mx[3];
     int res[3];

@@ -49,6 +49,9 @@ class KiloTrainStep:
             self.params.append(v)
             self.grads.append(self.grad[off:off + n].view(p.shape))
             off += n
+        names = [n for n, _, _ in KILO_TENSORS]
+        assert tuple(names[-4:]) == _REG_TENSORS, "colour-regularised tensors must be the last four of the flat buffer"
+        self._reg_begin = sum(sizes[:-4])
         self.reset_optimizer(lr)
         self._packed = None
         self._packed_t = None
@@ -90,11 +93,8 @@ class KiloTrainStep:
             g_acc = ops.mse_grad(acc, target_alpha.reshape(-1), self.loss)
         g_raw = kilo_ops.kilo_composite_backward(raw, ts, te, offsets, counts, r.ert, r.white_bkgd, g_rgb, None, g_acc)
         kilo_ops.kilo_backward(self._packed, self._packed_t, net.num_models, pts, d, ray_idx, g_raw, ws, grads=self.grads)
-        if distill and self.l2_reg > 0:
-            by_name = {n: i for i, (n, _, _) in enumerate(KILO_TENSORS)}
-            for name in _REG_TENSORS:
-                i = by_name[name]
-                kilo_ops.l2_reg(self.params[i], self.l2_reg, self.grads[i], self.loss)
+        if distill and self.l2_reg > 0:   # the four regularised tensors are the tail of the flat buffer: one launch
+            kilo_ops.l2_reg(self.flat[self._reg_begin:], self.l2_reg, self.grad[self._reg_begin:], self.loss)
         return {"rgb_map": rgb, "depth_map": depth, "alpha_map": acc}
 
     def step(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation"):
