@@ -215,6 +215,14 @@ int nrf_occ_bake(const float* packed_teacher, const float* aabb_host, const int*
                  int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
                  nrf_stream_t stream);
 
+/* The NeRF renderer's own occupancy grid: Renderer._build_occ_grid (src/models/nerf/renderer/volume_renderer.py:156-197).
+ * ONE point per voxel at torch.linspace(min, max, res)[i] per axis (:170-178), through `packed` (the network's
+ * default = coarse model, network.py:171-176) with zero view directions (:183-185); occ = raw sigma > threshold (:195). */
+int64_t nrf_occ_bake_vertices_workspace_bytes(int64_t n_cells);
+int nrf_occ_bake_vertices(const float* packed, const float* aabb_host, const int* res_host, float threshold,
+                          int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
+                          nrf_stream_t stream);
+
 /* ---- KiloNeRF training: what loss.backward() does in src/train/trainers/trainer.py:68-75 for the KiloNeRF
  * wrapper (src/train/trainers/kilonerf.py:34-63) ---- */
 

@@ -22,6 +22,7 @@ SYMBOLS = (
     "nrf_kilo_packed_floats", "nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward_workspace_bytes",
     "nrf_kilo_forward", "nrf_kilo_march_workspace_bytes", "nrf_kilo_march_count", "nrf_kilo_march_write",
     "nrf_kilo_composite", "nrf_occ_bake_workspace_bytes", "nrf_occ_bake",
+    "nrf_occ_bake_vertices_workspace_bytes", "nrf_occ_bake_vertices",
     "nrf_packed_bf16_bytes", "nrf_pack_weights_bf16", "nrf_mlp_forward_rays_bf16",
     "nrf_kilo_packed_bwd_floats", "nrf_kilo_pack_weights_transposed", "nrf_kilo_composite_backward",
     "nrf_kilo_backward_workspace_bytes", "nrf_kilo_backward", "nrf_l2_reg",
@@ -101,6 +102,10 @@ def lib() -> C.CDLL:
     L.nrf_occ_bake_workspace_bytes.argtypes = [I64]
     L.nrf_occ_bake.restype = INT
     L.nrf_occ_bake.argtypes = [P, P, P, F, I64, I64, P, P, I64, P]
+    L.nrf_occ_bake_vertices_workspace_bytes.restype = I64
+    L.nrf_occ_bake_vertices_workspace_bytes.argtypes = [I64]
+    L.nrf_occ_bake_vertices.restype = INT
+    L.nrf_occ_bake_vertices.argtypes = [P, P, P, F, I64, I64, P, P, I64, P]
     L.nrf_kilo_packed_floats.restype = I64
     L.nrf_kilo_packed_floats.argtypes = [INT]
     L.nrf_kilo_pack_weights.argtypes = [P, INT, P, P]

@@ -36,13 +36,25 @@ __global__ void occ_points_kernel(BakeGrid g, int64_t first_cell, int64_t n_cell
     }
 }
 
+// The NeRF renderer's own grid (src/models/nerf/renderer/volume_renderer.py:156-197, `_build_occ_grid`): ONE point per
+// voxel at torch.linspace(min, max, res)[i] per axis (:170-175, grid VERTICES spanning the whole box, not centres).
+__global__ void occ_vertex_points_kernel(BakeGrid g, int64_t first_cell, int64_t n_cells, float* __restrict__ pts) {
+    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= n_cells) return;
+    const int64_t cell = first_cell + p;
+    const int idx[3] = {int(cell / (int64_t(g.res[1]) * g.res[2])), int((cell / g.res[2]) % g.res[1]), int(cell % g.res[2])};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pts[p * 3 + a] = g.res[a] > 1 ? linspace_at(g.mn[a], g.mx[a], g.res[a], idx[a]) : g.mn[a];
+}
+
+template <int SUB>
 __global__ void occ_reduce_kernel(const float4* __restrict__ raw, int64_t n_cells, float threshold,
                                   unsigned char* __restrict__ occ) {
     const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= n_cells) return;
     bool any = false;
 #pragma unroll
-    for (int s = 0; s < 27; ++s) any |= raw[c * 27 + s].w > threshold;  // :217-220
+    for (int s = 0; s < SUB; ++s) any |= raw[c * SUB + s].w > threshold;  // :217-220 (kilonerf), :195 (nerf)
     occ[c] = any ? 1 : 0;
 }
 
@@ -50,39 +62,60 @@ inline int64_t a256(int64_t n) { return (n + 255) & ~int64_t(255); }
 
 }  // namespace
 
-// workspace: pts (27 n x 3) | zero dirs (27 n x 3) | raw (27 n x 4)
-NRF_EXPORT int64_t nrf_occ_bake_workspace_bytes(int64_t n_cells) {
+// workspace: pts (sub n x 3) | zero dirs (sub n x 3) | raw (sub n x 4)
+static int64_t bake_workspace_bytes(int64_t n_cells, int sub) {
     if (n_cells < 0 || n_cells > (int64_t(1) << 32)) return NRF_ERR_SHAPE;
-    return 2 * a256(n_cells * 27 * 12) + a256(n_cells * 27 * 16);
+    return 2 * a256(n_cells * sub * 12) + a256(n_cells * sub * 16);
 }
 
-NRF_EXPORT int nrf_occ_bake(const float* packed_teacher, const float* aabb_host, const int* res_host, float threshold,
-                            int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
-                            nrf_stream_t stream_) {
+static int bake(const float* packed, const float* aabb_host, const int* res_host, float threshold, int64_t first_cell,
+                int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes, bool vertices, nrf_stream_t stream_) {
     if (n_cells < 0 || first_cell < 0) return NRF_ERR_SHAPE;
     if (n_cells == 0) return NRF_OK;
-    if (!packed_teacher || !aabb_host || !res_host || !occ || !workspace) return NRF_ERR_NULL;
+    if (!packed || !aabb_host || !res_host || !occ || !workspace) return NRF_ERR_NULL;
     BakeGrid g;
     for (int a = 0; a < 3; ++a) g.mn[a] = aabb_host[a], g.mx[a] = aabb_host[3 + a], g.res[a] = res_host[a];
     if (g.res[0] <= 0 || g.res[1] <= 0 || g.res[2] <= 0) return NRF_ERR_SHAPE;
     if (first_cell + n_cells > int64_t(g.res[0]) * g.res[1] * g.res[2]) return NRF_ERR_SHAPE;
-    const int64_t need = nrf_occ_bake_workspace_bytes(n_cells);
+    const int sub = vertices ? 1 : 27;
+    const int64_t need = bake_workspace_bytes(n_cells, sub);
     if (need < 0) return int(need);
     if (workspace_bytes < need) return NRF_ERR_WORKSPACE;
     if (!nrf_aligned16(workspace)) return NRF_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int64_t np = n_cells * 27;
+    const int64_t np = n_cells * sub;
     char* wsb = static_cast<char*>(workspace);
     float* pts = reinterpret_cast<float*>(wsb);
     float* dirs = reinterpret_cast<float*>(wsb + a256(np * 12));
     float* raw = reinterpret_cast<float*>(wsb + 2 * a256(np * 12));
     nrf_launch_begin();
     if (hipMemsetAsync(dirs, 0, size_t(np) * 12, stream) != hipSuccess) return NRF_ERR_LAUNCH;
-    occ_points_kernel<<<dim3(unsigned((np + 255) / 256)), 256, 0, stream>>>(g, first_cell, n_cells, pts);
+    const dim3 pgrid(unsigned((np + 255) / 256)), cgrid(unsigned((n_cells + 255) / 256));
+    if (vertices) occ_vertex_points_kernel<<<pgrid, 256, 0, stream>>>(g, first_cell, n_cells, pts);
+    else occ_points_kernel<<<pgrid, 256, 0, stream>>>(g, first_cell, n_cells, pts);
     if (int st = nrf_launch_status()) return st;
-    if (int st = nrf_mlp_forward_points(packed_teacher, pts, dirs, np, raw, stream_)) return st;
+    if (int st = nrf_mlp_forward_points(packed, pts, dirs, np, raw, stream_)) return st;
     nrf_launch_begin();
-    occ_reduce_kernel<<<dim3(unsigned((n_cells + 255) / 256)), 256, 0, stream>>>(reinterpret_cast<const float4*>(raw), n_cells,
-                                                                             threshold, occ + first_cell);
+    if (vertices)
+        occ_reduce_kernel<1><<<cgrid, 256, 0, stream>>>(reinterpret_cast<const float4*>(raw), n_cells, threshold, occ + first_cell);
+    else
+        occ_reduce_kernel<27><<<cgrid, 256, 0, stream>>>(reinterpret_cast<const float4*>(raw), n_cells, threshold, occ + first_cell);
     return nrf_launch_status();
+}
+
+NRF_EXPORT int64_t nrf_occ_bake_workspace_bytes(int64_t n_cells) { return bake_workspace_bytes(n_cells, 27); }
+
+NRF_EXPORT int nrf_occ_bake(const float* packed_teacher, const float* aabb_host, const int* res_host, float threshold,
+                            int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
+                            nrf_stream_t stream) {
+    return bake(packed_teacher, aabb_host, res_host, threshold, first_cell, n_cells, occ, workspace, workspace_bytes, false,
+                stream);
+}
+
+NRF_EXPORT int64_t nrf_occ_bake_vertices_workspace_bytes(int64_t n_cells) { return bake_workspace_bytes(n_cells, 1); }
+
+NRF_EXPORT int nrf_occ_bake_vertices(const float* packed, const float* aabb_host, const int* res_host, float threshold,
+                                     int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace,
+                                     int64_t workspace_bytes, nrf_stream_t stream) {
+    return bake(packed, aabb_host, res_host, threshold, first_cell, n_cells, occ, workspace, workspace_bytes, true, stream);
 }

@@ -193,18 +193,24 @@ def kilo_composite(raw, t_start, t_end, offsets, counts, ert_eps: float, white_b
     return rgb, depth, acc
 
 
-def occ_bake(packed_teacher: torch.Tensor, aabb, res, threshold: float, chunk_cells: int = 1 << 20) -> torch.Tensor:
-    """Occupancy grid (rx,ry,rz) bool from the teacher's packed fine MLP (`_evaluate_grid`,
-    volumn_renderer.py:142-232), baked `chunk_cells` cells per launch group (1080 B of workspace per cell)."""
+def occ_bake(packed_teacher: torch.Tensor, aabb, res, threshold: float, chunk_cells: int = 1 << 20,
+             vertices: bool = False) -> torch.Tensor:
+    """Occupancy grid (rx,ry,rz) bool from a packed 8x256 MLP, baked `chunk_cells` cells per launch group.
+    Default: KiloNeRF's `_evaluate_grid` (volumn_renderer.py:142-232: 27 sub-points per cell, teacher fine model,
+    1080 B of workspace per cell).  ``vertices``: the NeRF renderer's `_build_occ_grid`
+    (nerf/renderer/volume_renderer.py:156-197: one linspace vertex per voxel, 40 B per cell)."""
     dev = packed_teacher.device
     _a, r, pa, pr = _grid_args(aabb, res)
     n = int(r[0]) * int(r[1]) * int(r[2])
     occ = torch.zeros(n, dtype=torch.uint8, device=dev)
     chunk = min(chunk_cells, n)
-    ws = torch.empty(int(lib().nrf_occ_bake_workspace_bytes(chunk)), dtype=torch.uint8, device=dev)
+    L = lib()
+    size_fn, bake_fn = ((L.nrf_occ_bake_vertices_workspace_bytes, L.nrf_occ_bake_vertices) if vertices else
+                        (L.nrf_occ_bake_workspace_bytes, L.nrf_occ_bake))
+    ws = torch.empty(max(int(size_fn(chunk)), 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         for first in range(0, n, chunk):
             m = min(chunk, n - first)
-            check(lib().nrf_occ_bake(_ptr(packed_teacher), pa, pr, float(threshold), first, m, _ptr(occ), _ptr(ws),
-                                     ws.numel(), _stream(occ)), "nrf_occ_bake")
+            check(bake_fn(_ptr(packed_teacher), pa, pr, float(threshold), first, m, _ptr(occ), _ptr(ws), ws.numel(),
+                          _stream(occ)), "nrf_occ_bake")
     return occ.view(int(r[0]), int(r[1]), int(r[2])).bool()

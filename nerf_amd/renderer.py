@@ -115,6 +115,59 @@ class Renderer(nn.Module):
         self._bwd_ws = None
         self._bins = None
         self._workspace = None
+        # the reference's second path: occupancy-grid skipping around the (coarse) network, its live `forward`
+        # (volume_renderer.py:37-47, 50-139); off unless asked for (render_occupancy / cfg.task_arg.occupancy_forward)
+        aabb = getattr(ta, "aabb", None) or {"min": [-1.0, -1.0, -1.0], "max": [1.0, 1.0, 1.0]}
+        self.scene_aabb = [float(v) for v in aabb["min"]] + [float(v) for v in aabb["max"]]
+        grid = getattr(ta, "grid_resolution", [16, 16, 16])
+        self.occ_grid_resolution = [int(g_) * int(getattr(ta, "occ_factor", 16)) for g_ in grid]
+        self.occ_grid = None
+        self.occupancy_forward = bool(getattr(ta, "occupancy_forward", False))
+        self.render_step_size, self.early_stop_eps = 1e-3, 1e-4   # nerfacc's defaults, which the reference does not override (:90-96)
+        self.last_num_samples = 0
+
+    # ---- occupancy-grid path (volume_renderer.py:50-139 + 156-197; sampling / compositing rule: DESIGN.md section 7) ----
+    @torch.no_grad()
+    def build_occ_grid(self, occ_thre: float = 0.01, device=None, chunk_cells: int = 1 << 22):
+        """`_build_occ_grid` (:156-197): the network's default (coarse) model at one linspace vertex per voxel of the
+        (grid_resolution * occ_factor)^3 grid, zero view directions, occupied = raw sigma > occ_thre."""
+        from . import kilo_ops
+        dev = torch.device(device) if device is not None else next(self.net.parameters()).device
+        packed = self._packed_model("model", dev)
+        self.occ_grid = kilo_ops.occ_bake(packed, self.scene_aabb, self.occ_grid_resolution, occ_thre, chunk_cells,
+                                          vertices=True).to(torch.uint8)
+        return self.occ_grid
+
+    @torch.no_grad()
+    def render_occupancy(self, batch):
+        """The reference's live `forward` (:50-139): occupancy-grid sampling between near and far, the network at the
+        interval mid-points (`self.net(pts, viewdirs[ray])`: default = coarse model, directions as given, :104-112),
+        packed compositing with the background (:123-132).  The sampling / termination / compositing rule is this
+        repository's (nerfacc is absent and unpinned: kilo.hip), with nerfacc's default step
+        1e-3 and early-stop threshold 1e-4.  Returns fine_rgb_map (B,R,3), fine_depth_map (B,R,1), alpha_map (B,R,1)."""
+        from . import kilo_ops
+        xyz, viewdirs = batch["xyz"], batch["viewdirs"]
+        if not xyz.is_cuda:
+            raise NrfError("batch tensors must be on a GPU: this renderer has no CPU path")
+        B, R, _ = xyz.shape
+        o = xyz.reshape(-1, 3).to(torch.float32).contiguous()
+        d = viewdirs.reshape(-1, 3).to(torch.float32).contiguous()
+        dev = o.device
+        if self.occ_grid is None:
+            self.build_occ_grid(device=dev)                       # the reference bakes it in __init__ (:46-47)
+        if self.occ_grid.device != dev:
+            self.occ_grid = self.occ_grid.to(dev)
+        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, self.occ_grid, self.scene_aabb, self.near, self.far,
+                                                                    self.render_step_size)
+        self.last_num_samples = n = int(pts.shape[0])
+        if n:
+            raw = ops.mlp_forward_points(self._packed_model("model", dev), pts, d.index_select(0, ray_idx.long()))
+        else:
+            raw = torch.empty((0, 4), dtype=torch.float32, device=dev)
+        rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.early_stop_eps, self.white_bkgd > 0)
+        rgb, depth, acc = rgb.view(B, R, 3), depth.view(B, R, 1), acc.view(B, R, 1)
+        return {"fine_rgb_map": rgb, "fine_depth_map": depth, "alpha_map": acc,
+                "rgb_map": rgb, "depth_map": depth, "acc_map": acc}
 
     # ---- weights ---------------------------------------------------------------------
     def _packed_model(self, name: str, device, bf16: bool = False) -> torch.Tensor:
@@ -181,6 +234,8 @@ class Renderer(nn.Module):
         return self.forward(batch, is_training)
 
     def forward(self, batch, is_training: bool = True):
+        if self.occupancy_forward and not (is_training and torch.is_grad_enabled()):
+            return self.render_occupancy(batch)
         xyz, viewdirs = batch["xyz"], batch["viewdirs"]
         _ = batch["gt_rgb"]  # the classic path requires the key (:209, :276)
         if xyz.ndim != 3 or xyz.shape[0] != 1:

@@ -300,3 +300,39 @@ def loss(out: dict, gt: torch.Tensor) -> torch.Tensor:
 
 def state_dict_from_arrays(arrs: dict) -> dict:
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in arrs.items()}
+
+
+# --------------------------------------------------------------------------------------
+# the renderer's occupancy-grid path -- volume_renderer.py:50-139 (live `forward`), 156-197 (`_build_occ_grid`)
+# --------------------------------------------------------------------------------------
+def build_occ_grid(sd: dict, aabb_min, aabb_max, res, occ_thre: float = 0.01, want_sigma: bool = False):
+    """``_build_occ_grid`` with the same torch ops: ``linspace(min, max, res)`` per axis (:170-172), meshgrid 'ij'
+    (:175), the network's default (coarse) model with zero view directions (:183-185), ``sigma > occ_thre`` (:195).
+    The network part is pinned by the network fixtures; the grid construction is torch's own linspace."""
+    axes = [torch.linspace(float(aabb_min[a]), float(aabb_max[a]), int(res[a])) for a in range(3)]
+    gx, gy, gz = torch.meshgrid(*axes, indexing="ij")
+    pts = torch.stack([gx, gy, gz], -1).view(-1, 3)
+    with torch.no_grad():
+        sig = network_forward(sd, pts, torch.zeros_like(pts))[:, 3]
+    occ = (sig > occ_thre).view(*[int(r) for r in res]).numpy()
+    return (occ, sig.view(*[int(r) for r in res]).numpy()) if want_sigma else occ
+
+
+def render_occupancy(sd: dict, rays_o, rays_d, occ, aabb_min, aabb_max, near=2.0, far=6.0, step=1e-3, early_stop_eps=1e-4,
+                     white_bkgd=True):
+    """The live ``forward`` (:50-139) under this repository's sampling / compositing rule (**parity unpinned**: the
+    reference delegates both to nerfacc, see oracle/kilo_oracle.py): intervals of ``step`` through the occupancy
+    grid, ``self.net(pts, viewdirs[ray])`` = coarse model with the directions as given (:104-112), packed
+    compositing + background (:123-132).  Shapes for batch size 1."""
+    from . import kilo_oracle as K
+    o, d = np.asarray(rays_o, np.float32).reshape(-1, 3), np.asarray(rays_d, np.float32).reshape(-1, 3)
+    pts, ri, ts, te, off, cnt = K.march(o, d, occ, aabb_min, aabb_max, near, far, step)
+    if len(pts):
+        with torch.no_grad():
+            raw = network_forward(sd, torch.from_numpy(pts), torch.from_numpy(d[ri])).numpy()
+    else:
+        raw = np.zeros((0, 4), np.float32)
+    rgb, depth, acc = K.composite_packed(raw, ts, te, off, cnt, early_stop_eps, white_bkgd)
+    R = len(off)
+    return {"fine_rgb_map": rgb.reshape(1, R, 3).astype(np.float32), "fine_depth_map": depth.reshape(1, R, 1).astype(np.float32),
+            "alpha_map": acc.reshape(1, R, 1).astype(np.float32), "n_samples": int(cnt.sum())}

@@ -333,3 +333,47 @@ def test_sample_fine_bit_exact_at_scale(dev, n_imp, n_rays):
         assert np.array_equal(idx[sl].astype(np.int64), i_ref)
         assert np.array_equal(fine[sl], f_ref)
         assert np.array_equal(z[sl], O.merge_sort(zc[sl], f_ref))
+
+
+def test_occupancy_grid_and_occupancy_forward_vs_oracle(dev):
+    """The reference renderer's second path (volume_renderer.py:50-139, 156-197): vertex occupancy bake against the
+    oracle's torch restatement, then occupancy-grid rendering of the coarse network against the oracle under this
+    repository's sampling rule (nerfacc absent: parity unpinned)."""
+    from nerf_amd.camera import LEGO_CAMERA_ANGLE_X, pose_spherical
+    from nerf_amd.config import default_cfg
+    from nerf_amd.network import Network
+    from nerf_amd.renderer import Renderer
+    from nerf_amd.weights import make_state_dict
+    from oracle import nerf_oracle as O
+    sd = make_state_dict(5, 30.0, -1.0)                      # density bias -1: about half of the box is empty
+    net = Network()
+    net.load_state_dict(sd)
+    cfg = default_cfg(perturb=0, grid_resolution=[2, 2, 2], occ_factor=12,
+                      aabb={"min": [-1.0, -1.0, -1.0], "max": [1.0, 1.0, 1.0]})
+    r = Renderer(net.to(dev), cfg)
+    assert r.occ_grid_resolution == [24, 24, 24]
+    thr = 0.01
+    occ = r.build_occ_grid(thr).cpu().numpy()
+    ref_occ, sig = O.build_occ_grid(sd, [-1.0] * 3, [1.0] * 3, [24, 24, 24], thr, want_sigma=True)
+    clear = np.abs(sig - thr) > 2e-4 * 30                    # fp32 rounding next to the threshold may flip a voxel
+    assert clear.mean() > 0.97 and np.array_equal(occ.astype(bool)[clear], ref_occ[clear])
+    assert 0.05 < occ.mean() < 0.95
+    r.occ_grid = _t(ref_occ.astype(np.uint8), dev)           # same grid on both sides from here on
+    r.render_step_size = 0.01                                # keeps the CPU oracle to ~20 k samples
+    o, d = O.raygen(pose_spherical(20.0, -30.0, 4.031), 12, 12, LEGO_CAMERA_ANGLE_X * 0.9)
+    o, d = o.reshape(-1, 3).astype(np.float32), d.reshape(-1, 3).astype(np.float32)
+    out = r.render_occupancy({"xyz": _t(o, dev)[None], "viewdirs": _t(d, dev)[None]})
+    ref = O.render_occupancy(sd, o, d, ref_occ.astype(np.uint8), [-1.0] * 3, [1.0] * 3, 2.0, 6.0, 0.01, r.early_stop_eps, True)
+    assert r.last_num_samples == ref["n_samples"] > 2000
+    assert out["fine_rgb_map"].shape == (1, 144, 3) and out["alpha_map"].shape == (1, 144, 1)
+    for k, tol in (("fine_rgb_map", 1e-4), ("alpha_map", 1e-4), ("fine_depth_map", 5e-4)):
+        assert np.abs(out[k].cpu().numpy() - ref[k]).max() < tol, k
+    # forward() takes this path for inference when the switch is on, and the classic path otherwise
+    r.occupancy_forward = True
+    batch = {"xyz": _t(o, dev)[None], "viewdirs": _t(d, dev)[None], "gt_rgb": _t(o, dev)[None]}
+    with torch.no_grad():
+        again = r(batch, is_training=False)
+    assert torch.equal(again["fine_rgb_map"], out["fine_rgb_map"]) and "coarse_rgb_map" not in again
+    r.occupancy_forward = False
+    with torch.no_grad():
+        assert "coarse_rgb_map" in r(batch, is_training=False)
