@@ -269,13 +269,14 @@ __device__ __forceinline__ int map_col(const ColMap& cm, int c) {
 // Sum of the split-P partials, scattered into the reference's (out, in) layout.  A block is 256 columns x kRedY
 // slice groups: the 256 slices of one element are summed by kRedY threads (16 independent loads in flight each) and
 // combined through LDS -- with one thread per element the 12 reduces of a backward pass ran at 52 GB/s.
-constexpr int kRedY = 4;
-__global__ __launch_bounds__(256 * kRedY) void wgrad_reduce_kernel(const float* __restrict__ partial,
+// (the summation order of a bias element changes with kRedY; the weight elements' order does too: fp32 sums)
+constexpr int kRedY = 16, kRedX = 64;
+__global__ __launch_bounds__(kRedX * kRedY) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                                   const float* __restrict__ pbias, int n_slices, int M,
                                                                   int K, int m_valid, ColMap cm, float* __restrict__ gw,
                                                                   int ldw, float* __restrict__ gb) {
-    __shared__ float s_part[kRedY][256];
-    const int idx = blockIdx.x * 256 + threadIdx.x, y = threadIdx.y;
+    __shared__ float s_part[kRedY][kRedX];
+    const int idx = blockIdx.x * kRedX + threadIdx.x, y = threadIdx.y;
     const bool in = idx < M * K;
     float s = 0.f;
     if (in) {
@@ -294,9 +295,21 @@ __global__ __launch_bounds__(256 * kRedY) void wgrad_reduce_kernel(const float* 
             gw[int64_t(m) * ldw + col] = t;
         }
     }
-    if (y == 1 && idx < m_valid) {
-        float t = 0.f;
-        for (int sl = 0; sl < n_slices; ++sl) t += pbias[int64_t(sl) * M + idx];
+    // bias: the same split over the slice groups (one thread walking all 256 slices was a 256-deep load chain:
+    // 60 of the kernel's 65 microseconds)
+    __syncthreads();
+    const bool bin = idx < m_valid;
+    float bsum = 0.f;
+    if (bin) {
+#pragma unroll 16
+        for (int sl = y; sl < n_slices; sl += kRedY) bsum += pbias[int64_t(sl) * M + idx];
+    }
+    s_part[y][threadIdx.x] = bsum;
+    __syncthreads();
+    if (y == 0 && bin) {
+        float t = s_part[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < kRedY; ++k) t += s_part[k][threadIdx.x];
         gb[idx] = t;
     }
 }
@@ -372,7 +385,7 @@ NRF_EXPORT int nrf_mlp_backward(const float* packed, const float* packed_t, cons
     };
     auto reduce = [&](int M, int K, int m_valid, ColMap cm, int layer) {
         const int total = M * K;
-        wgrad_reduce_kernel<<<(total + 255) / 256, dim3(256, kRedY), 0, stream>>>(partial, pbias, slices, M, K, m_valid, cm,
+        wgrad_reduce_kernel<<<(total + kRedX - 1) / kRedX, dim3(kRedX, kRedY), 0, stream>>>(partial, pbias, slices, M, K, m_valid, cm,
                                                                      grad_flat + woff[layer], kLayerIn[layer],
                                                                      grad_flat + boff[layer]);
     };
