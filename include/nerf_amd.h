@@ -98,6 +98,10 @@ int64_t nrf_packed_bf16_bytes(void);
 int nrf_pack_weights_bf16(const float* const* w, const float* const* b, void* packed_bf16, nrf_stream_t stream);
 int nrf_mlp_forward_rays_bf16(const void* packed_bf16, const float* rays_o, const float* rays_d, const float* z,
                               int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream);
+/* Network.forward on a flat batch (network.py:184-186) with the bf16 MLP: pts (n, 3), dirs (n, 3) used as given
+ * (not normalised), any n.  raw: (n, 4). */
+int nrf_mlp_forward_points_bf16(const void* packed_bf16, const float* pts, const float* dirs, int64_t n_points,
+                                float* raw, nrf_stream_t stream);
 
 /* ---- alpha compositing: volume_renderer.py:222-224, 236-265 / 291-334 --------------- */
 

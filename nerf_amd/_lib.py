@@ -23,7 +23,7 @@ SYMBOLS = (
     "nrf_kilo_forward", "nrf_kilo_march_workspace_bytes", "nrf_kilo_march_count", "nrf_kilo_march_write",
     "nrf_kilo_composite", "nrf_occ_bake_workspace_bytes", "nrf_occ_bake",
     "nrf_occ_bake_vertices_workspace_bytes", "nrf_occ_bake_vertices",
-    "nrf_packed_bf16_bytes", "nrf_pack_weights_bf16", "nrf_mlp_forward_rays_bf16",
+    "nrf_packed_bf16_bytes", "nrf_pack_weights_bf16", "nrf_mlp_forward_rays_bf16", "nrf_mlp_forward_points_bf16",
     "nrf_kilo_packed_bwd_floats", "nrf_kilo_pack_weights_transposed", "nrf_kilo_composite_backward",
     "nrf_kilo_backward_workspace_bytes", "nrf_kilo_backward", "nrf_l2_reg",
 )
@@ -98,6 +98,8 @@ def lib() -> C.CDLL:
     L.nrf_pack_weights_bf16.argtypes = [P, P, P, P]
     L.nrf_mlp_forward_rays_bf16.restype = INT
     L.nrf_mlp_forward_rays_bf16.argtypes = [P, P, P, P, I64, I64, INT, P, P]
+    L.nrf_mlp_forward_points_bf16.restype = INT
+    L.nrf_mlp_forward_points_bf16.argtypes = [P, P, P, I64, P, P]
     L.nrf_occ_bake_workspace_bytes.restype = I64
     L.nrf_occ_bake_workspace_bytes.argtypes = [I64]
     L.nrf_occ_bake.restype = INT

@@ -243,11 +243,14 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
 __device__ __forceinline__ float bf_lo(unsigned r) { return __uint_as_float(r << 16); }
 __device__ __forceinline__ float bf_hi(unsigned r) { return __uint_as_float(r & 0xffff0000u); }
 
-// Persistent, one 4-wave workgroup per CU, one wave per SIMD; a wave's tile = 64 consecutive samples of one ray.
+// Persistent, one 4-wave workgroup per CU, one wave per SIMD; a wave's tile = 64 consecutive samples of one ray, or
+// (POINTS: Network.forward on a flat batch, network.py:184-186) 64 consecutive points with their own directions,
+// used as given; then rays_o = pts (n, 3), rays_d = dirs (n, 3), n_points bounds the last tile.
+template <bool POINTS>
 __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict__ packed, const float* __restrict__ rays_o,
                                                           const float* __restrict__ rays_d, const float* __restrict__ zbuf,
                                                           int64_t z_stride, int tiles_per_ray, int64_t n_tiles,
-                                                          int64_t n_groups, float4* __restrict__ raw) {
+                                                          int64_t n_groups, int64_t n_points, float4* __restrict__ raw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -268,24 +271,37 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
         int64_t tile = tg * 4 + wave;
         const bool valid = tile < n_tiles;
         if (!valid) tile = n_tiles - 1;
-        const int64_t ray = tile / tiles_per_ray;
-        const int s0 = int(tile - ray * tiles_per_ray) * 64;
-        const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
-        float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
-        const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // volume_renderer.py:230 (torch's 3-element norm)
-        dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
         u32x4 pe[2][2][2], dpe[2][2];
+        if constexpr (POINTS) {
 #pragma unroll
-        for (int set = 0; set < 2; ++set) {
-            const float zz = zbuf[ray * z_stride + s0 + 32 * set + j];
-            const float px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
-            const float py = __fadd_rn(oy, __fmul_rn(zz, dy));
-            const float pz = __fadd_rn(oz, __fmul_rn(zz, dz));
-            pack_tile(encode_block<10, 0>(px, py, pz, h), pe[set][0]);
-            pack_tile(encode_block<10, 1>(px, py, pz, h), pe[set][1]);
+            for (int set = 0; set < 2; ++set) {
+                int64_t pt = tile * 64 + 32 * set + j;
+                pt = pt < n_points ? pt : n_points - 1;   // tail lanes repeat the last point (stores are masked)
+                const float px = rays_o[pt * 3], py = rays_o[pt * 3 + 1], pz = rays_o[pt * 3 + 2];
+                const float dx = rays_d[pt * 3], dy = rays_d[pt * 3 + 1], dz = rays_d[pt * 3 + 2];
+                pack_tile(encode_block<10, 0>(px, py, pz, h), pe[set][0]);
+                pack_tile(encode_block<10, 1>(px, py, pz, h), pe[set][1]);
+                pack_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[set]);
+            }
+        } else {
+            const int64_t ray = tile / tiles_per_ray;
+            const int s0 = int(tile - ray * tiles_per_ray) * 64;
+            const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+            float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+            const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // volume_renderer.py:230 (torch's 3-element norm)
+            dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
+#pragma unroll
+            for (int set = 0; set < 2; ++set) {
+                const float zz = zbuf[ray * z_stride + s0 + 32 * set + j];
+                const float px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
+                const float py = __fadd_rn(oy, __fmul_rn(zz, dy));
+                const float pz = __fadd_rn(oz, __fmul_rn(zz, dz));
+                pack_tile(encode_block<10, 0>(px, py, pz, h), pe[set][0]);
+                pack_tile(encode_block<10, 1>(px, py, pz, h), pe[set][1]);
+            }
+            pack_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[0]);  // both sets are samples of the same ray
+            dpe[1][0] = dpe[0][0], dpe[1][1] = dpe[0][1];
         }
-        pack_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[0]);  // both sets are samples of the same ray
-        dpe[1][0] = dpe[0][0], dpe[1][1] = dpe[0][1];
 
         u32x4 XA[2][8][2], XB[2][8][2];
         {
@@ -341,7 +357,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
             float r = er.acc[set][0], g = er.acc[set][1], b = er.acc[set][2];
             r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32);
             const float sg = sigma[set] + __shfl_xor(sigma[set], 32);
-            if (h == 0 && valid) raw[tile * 64 + 32 * set + j] = make_float4(r + rb[0], g + rb[1], b + rb[2], sg + ab);
+            const int64_t dst = tile * 64 + 32 * set + j;
+            if (h == 0 && valid && (!POINTS || dst < n_points)) raw[dst] = make_float4(r + rb[0], g + rb[1], b + rb[2], sg + ab);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
@@ -388,6 +405,28 @@ NRF_EXPORT int nrf_pack_weights_bf16(const float* const* w, const float* const* 
     return nrf_launch_status();
 }
 
+template <bool POINTS>
+static int launch_bf16(const void* packed_bf16, const float* a, const float* b, const float* z, int64_t z_stride,
+                       int tiles_per_ray, int64_t n_tiles, int64_t n_points, float* raw, nrf_stream_t stream) {
+    const int64_t groups = (n_tiles + 3) / 4;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    static bool attr_set[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16_kernel<POINTS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kBLdsBytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const unsigned grid = unsigned(groups < cus ? groups : cus);
+    nrf_launch_begin();
+    mlp_bf16_kernel<POINTS><<<dim3(grid), 256, kBLdsBytes, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const char*>(packed_bf16), a, b, z, z_stride, tiles_per_ray, n_tiles, groups, n_points,
+        reinterpret_cast<float4*>(raw));
+    return nrf_launch_status();
+}
+
 NRF_EXPORT int nrf_mlp_forward_rays_bf16(const void* packed_bf16, const float* rays_o, const float* rays_d, const float* z,
                                          int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream) {
     if (n_rays < 0 || n_samples <= 0 || n_samples % 64 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
@@ -397,22 +436,15 @@ NRF_EXPORT int nrf_mlp_forward_rays_bf16(const void* packed_bf16, const float* r
     if (!nrf_aligned16(packed_bf16) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
     if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
     const int tiles_per_ray = n_samples / 64;
-    const int64_t n_tiles = n_rays * tiles_per_ray;
-    const int64_t groups = (n_tiles + 3) / 4;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (cus <= 0) cus = 256;
-    static bool attr_set[64] = {};
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kBLdsBytes) != hipSuccess)
-            return NRF_ERR_LAUNCH;
-        attr_set[dev] = true;
-    }
-    const unsigned grid = unsigned(groups < cus ? groups : cus);
-    nrf_launch_begin();
-    mlp_bf16_kernel<<<dim3(grid), 256, kBLdsBytes, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const char*>(packed_bf16), rays_o, rays_d, z, z_stride, tiles_per_ray, n_tiles, groups,
-        reinterpret_cast<float4*>(raw));
-    return nrf_launch_status();
+    return launch_bf16<false>(packed_bf16, rays_o, rays_d, z, z_stride, tiles_per_ray, n_rays * tiles_per_ray, 0, raw, stream);
+}
+
+// Network.forward on a flat batch with the bf16 MLP: pts (n, 3), dirs (n, 3) used as given.  raw: (n, 4).
+NRF_EXPORT int nrf_mlp_forward_points_bf16(const void* packed_bf16, const float* pts, const float* dirs, int64_t n_points,
+                                           float* raw, nrf_stream_t stream) {
+    if (n_points < 0 || n_points > (int64_t(1) << 40)) return NRF_ERR_SHAPE;
+    if (n_points == 0) return NRF_OK;
+    if (!packed_bf16 || !pts || !dirs || !raw) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed_bf16) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    return launch_bf16<true>(packed_bf16, pts, dirs, nullptr, 0, 0, (n_points + 63) / 64, n_points, raw, stream);
 }

@@ -149,6 +149,18 @@ def mlp_forward_points(packed, pts, dirs) -> torch.Tensor:
     return raw
 
 
+def mlp_forward_points_bf16(packed_bf16, pts, dirs) -> torch.Tensor:
+    pts, dirs = _f32(pts, "pts"), _f32(dirs, "dirs")
+    n = pts.shape[0]
+    if dirs.shape[0] != n:
+        raise _lib.NrfError(f"dirs has {dirs.shape[0]} rows for {n} points")
+    raw = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(raw.device):
+        check(lib().nrf_mlp_forward_points_bf16(_ptr(packed_bf16), _ptr(pts), _ptr(dirs), n, _ptr(raw), _stream(raw)),
+              "nrf_mlp_forward_points_bf16")
+    return raw
+
+
 def composite(raw, z, white_bkgd: bool = True, want_weights: bool = True):
     raw, z = _f32(raw, "raw"), _f32(z, "z")
     R, S = raw.shape[0], raw.shape[1]

@@ -161,7 +161,9 @@ class Renderer(nn.Module):
                                                                     self.render_step_size)
         self.last_num_samples = n = int(pts.shape[0])
         if n:
-            raw = ops.mlp_forward_points(self._packed_model("model", dev), pts, d.index_select(0, ray_idx.long()))
+            bf16 = self.mlp_dtype == "bf16"
+            fwd = ops.mlp_forward_points_bf16 if bf16 else ops.mlp_forward_points
+            raw = fwd(self._packed_model("model", dev, bf16), pts, d.index_select(0, ray_idx.long()))
         else:
             raw = torch.empty((0, 4), dtype=torch.float32, device=dev)
         rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.early_stop_eps, self.white_bkgd > 0)

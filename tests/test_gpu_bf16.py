@@ -110,3 +110,37 @@ def test_bf16_ragged_tile_groups(dev):
     for n in (1, 2, 3, 5, 1030):
         part = ops.mlp_forward_rays_bf16(pb, o[:n], d[:n], z[:n])
         assert torch.equal(part, full[:n]), n
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 70001])
+def test_mlp_points_bf16_vs_bf16_oracle(dev, n):
+    """nrf_mlp_forward_points_bf16: flat batch with per-point directions used as given, any n (ragged last tile)."""
+    from nerf_amd import ops
+    from nerf_amd.weights import make_state_dict, make_state_dict_arrays
+    from oracle import nerf_oracle as O
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)                     # not normalised
+    gain = 30.0
+    packed = ops.pack_state_dict_bf16(make_state_dict_arrays(2, gain, 1.0), "model", dev)
+    raw = ops.mlp_forward_points_bf16(packed, _t(pts, dev), _t(dirs, dev))
+    assert raw.shape == (n, 4) and torch.isfinite(raw).all()
+    m = min(n, 4000)
+    with torch.no_grad():
+        ref = O.network_forward(make_state_dict(2, gain, 1.0), torch.from_numpy(pts[:m]), torch.from_numpy(dirs[:m]), bf16=True).numpy()
+        ref_tail = O.network_forward(make_state_dict(2, gain, 1.0), torch.from_numpy(pts[-64:]), torch.from_numpy(dirs[-64:]),
+                                     bf16=True).numpy()
+    got = raw.cpu().numpy()
+    for g, r in ((got[:m], ref), (got[-64:], ref_tail)):
+        assert np.abs(g[:, :3] - r[:, :3]).max() < 1e-3
+        assert np.abs(g[:, 3] - r[:, 3]).max() < 1e-3 * gain
+    # same values as the ray entry point when the points are a ray's samples and the directions its unit direction
+    if n == 64:
+        o = _t(np.array([[0.1, -0.2, 3.5]], np.float32), dev)
+        d = _t(np.array([[0.05, 0.1, -1.0]], np.float32), dev)
+        z = torch.linspace(2, 6, 64, device=dev)
+        dhat = d / torch.norm(d, dim=-1, keepdim=True)
+        p = (o + z[:, None] * dhat).contiguous()
+        a = ops.mlp_forward_rays_bf16(packed, o, d, z)[0]
+        b = ops.mlp_forward_points_bf16(packed, p, dhat.expand(64, 3).contiguous())
+        assert torch.allclose(a, b, atol=2e-3 * gain, rtol=0)                # point construction differs in rounding only

@@ -41,3 +41,9 @@ print(f"render_occupancy: {t_occ * 1e3:.1f} ms, {r.last_num_samples / 1e6:.1f} M
 with torch.no_grad():
     t_cls, _ = timed(lambda: r(batch, is_training=False), 1)
 print(f"classic 64 + 128: {t_cls * 1e3:.1f} ms")
+rb = Renderer(net, default_cfg(perturb=0), mlp_dtype="bf16")
+rb.occ_grid = r.occ_grid
+t_b, out_b = timed(lambda: rb.render_occupancy(batch))
+err = float((out_b["fine_rgb_map"] - out["fine_rgb_map"]).abs().max())
+print(f"render_occupancy, bf16 MLP: {t_b * 1e3:.1f} ms ({rb.last_num_samples * 1186816 / t_b / 1e12:.0f} TFLOP/s over the whole call), "
+      f"max |rgb - fp32| {err:.2e}")
