@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict
 //
 // What bounds it (measured): on gfx950 the f32 MFMA runs at the vector-ALU rate (64 cycles per
 // 32x32x2; 157 TF is also the VALU peak) and VALU work does not hide under it: ablations show tile time = its 96
-// MFMAs (6.1k cycles) PLUS its ~1200 VALU instructions (sin/cos encoding ~950 of them, ~4.7 cycles each).
+// MFMAs (6.1k cycles) PLUS its VALU instructions (~1200 with every sin/cos through the polynomial, ~4.7 cycles
+// each; encode_pe_doubling takes the odd octaves by a double-angle step and removes ~260 of them).
 // Hand-interleaving the next tile's encoding into the MFMA gaps, and two waves per SIMD, both measured no faster,
 // so this is the plain form: one wave per SIMD, the cell's whole weight set in registers for the job (24 float4 of
 // matrix operands, biases as accumulator initialisers, head rows), gathers prefetched three tiles ahead.
@@ -238,15 +239,14 @@ __global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restric
                 id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_n = di_nn;
             }
             f32x16 x[2];
-            x[0] = encode_block<10, 0>(px, py, pz, h);
-            x[1] = encode_block<10, 1>(px, py, pz, h);
+            encode_pe_doubling<10>(px, py, pz, h, x);
             x[0] = relu16(tiny_layer<2>(w, bias[0], x));                    // pts_linears 0 (network.py:132-138)
             x[0] = relu16(tiny_layer<1>(w + 8, bias[1], x));                // pts_linears 1
             float sigma = 0.f;                                              // sigma_linear (:142-144)
 #pragma unroll
             for (int t = 0; t < 16; ++t) sigma = fmaf(sw[t], x[0][t], sigma);
             x[0] = tiny_layer<1>(w + 12, bias[2], x);                       // feature_linear (:147-149), no activation
-            x[1] = encode_block<4, 0>(dx, dy, dz, h);
+            encode_pe_doubling<4>(dx, dy, dz, h, x + 1);
             const f32x16 hv = relu16(tiny_layer<2>(w + 16, bias[3], x));    // view_linears on cat([feature, dirs]) (:152-156)
             float r = 0.f, g = 0.f, b = 0.f;                                // rgb_linear (:159-161)
 #pragma unroll

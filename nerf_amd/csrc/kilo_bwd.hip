@@ -243,8 +243,7 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
 
                 // ---- forward chain again (kilo_mlp_kernel), keeping every layer's input ----
                 f32x16 x[2];
-                x[0] = encode_block<10, 0>(px, py, pz, h);
-                x[1] = encode_block<10, 1>(px, py, pz, h);
+                encode_pe_doubling<10>(px, py, pz, h, x);
                 tile_store(T, 0, x[0], j, h);
                 {
                     f32x16 x1 = x[1];
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                 const f32x16 h0 = relu16(tiny_layer_g<2>(w4, bias(0), x));
                 const f32x16 h1 = relu16(tiny_layer_g<1>(w4 + 8 * 64, bias(1), &h0));
                 x[0] = tiny_layer_g<1>(w4 + 12 * 64, bias(2), &h1);                    // feature, no activation
-                x[1] = encode_block<4, 0>(dx, dy, dz, h);
+                encode_pe_doubling<4>(dx, dy, dz, h, x + 1);
                 const f32x16 hv = relu16(tiny_layer_g<2>(w4 + 16 * 64, bias(3), x));
 
                 // next tile, stage 2 (its index arrived during the forward chain)

@@ -279,9 +279,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
                 pt = pt < n_points ? pt : n_points - 1;   // tail lanes repeat the last point (stores are masked)
                 const float px = rays_o[pt * 3], py = rays_o[pt * 3 + 1], pz = rays_o[pt * 3 + 2];
                 const float dx = rays_d[pt * 3], dy = rays_d[pt * 3 + 1], dz = rays_d[pt * 3 + 2];
-                pack_tile(encode_block<10, 0>(px, py, pz, h), pe[set][0]);
-                pack_tile(encode_block<10, 1>(px, py, pz, h), pe[set][1]);
-                pack_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[set]);
+                f32x16 enc[2], denc[1];
+                encode_pe_doubling<10>(px, py, pz, h, enc);
+                encode_pe_doubling<4>(dx, dy, dz, h, denc);
+                pack_tile(enc[0], pe[set][0]);
+                pack_tile(enc[1], pe[set][1]);
+                pack_tile(denc[0], dpe[set]);
             }
         } else {
             const int64_t ray = tile / tiles_per_ray;
@@ -296,10 +299,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
                 const float px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
                 const float py = __fadd_rn(oy, __fmul_rn(zz, dy));
                 const float pz = __fadd_rn(oz, __fmul_rn(zz, dz));
-                pack_tile(encode_block<10, 0>(px, py, pz, h), pe[set][0]);
-                pack_tile(encode_block<10, 1>(px, py, pz, h), pe[set][1]);
+                f32x16 enc[2];
+                encode_pe_doubling<10>(px, py, pz, h, enc);
+                pack_tile(enc[0], pe[set][0]);
+                pack_tile(enc[1], pe[set][1]);
             }
-            pack_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[0]);  // both sets are samples of the same ray
+            f32x16 denc[1];
+            encode_pe_doubling<4>(dx, dy, dz, h, denc);
+            pack_tile(denc[0], dpe[0]);  // both sets are samples of the same ray
             dpe[1][0] = dpe[0][0], dpe[1][1] = dpe[0][1];
         }
 
