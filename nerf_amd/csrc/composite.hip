@@ -12,11 +12,12 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+// The kernel is one HBM pass, but with libm's expf / IEEE division and ds_bpermute scans it was bound by its ~640
+// instructions per ray, not by memory.  exp and the sigmoid's reciprocal are the hardware v_exp_f32 / v_rcp_f32
+// (1 ulp each; the argument scaling adds |x| * 6e-8 relative to exp(x), which alpha = 1 - exp(-x) and the sigmoid
+// turn into < 3e-8 absolute), the scans run on DPP (nrf_common.h).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + fast_exp(-x)); }
 
 template <int NCHUNK>
 __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
@@ -47,28 +48,22 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
         const int s = c * 64 + lane;
         const float delta = (s + 1 < S) ? zn[c] - zv[c] : 1e10f;          // :222-224
         const float sigma = fmaxf(rv[c].w, 0.f);                          // :244
-        const float alpha = 1.f - expf(-sigma * delta);                   // :248
+        const float alpha = 1.f - fast_exp(-sigma * delta);               // :248
         const float om = 1.f - alpha;
-        float p = om;  // inclusive product scan over the 64 lanes
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float t = __shfl_up(p, off);
-            if (lane >= off) p *= t;
-        }
-        float ex = __shfl_up(p, 1);
-        if (lane == 0) ex = 1.f;
-        const float T = carry * ex;                                       // :249-250 exclusive cumprod
-        carry *= __shfl(p, 63);
+        const float p = nrf_wave_scan_mul(om);  // inclusive product scan over the 64 lanes
+        const float T = carry * nrf_lane_shr1(1.f, p);                    // :249-250 exclusive cumprod
+        carry *= nrf_read_lane63(p);
         const float w = T * alpha;                                        // :252
         if (weights) weights[ray * S + s] = w;
-        sr += w / (1.f + expf(-rv[c].x));                                 // :246 sigmoid, :254
-        sg += w / (1.f + expf(-rv[c].y));
-        sb += w / (1.f + expf(-rv[c].z));
+        sr += w * fast_sigmoid(rv[c].x);                                  // :246 sigmoid, :254
+        sg += w * fast_sigmoid(rv[c].y);
+        sb += w * fast_sigmoid(rv[c].z);
         sa += w;                                                          // :256
         sd += w * zv[c];                                                  // :263
     }
-    sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sa = wave_sum(sa), sd = wave_sum(sd);
-    if (lane == 0) {
+    sr = nrf_wave_scan_add(sr), sg = nrf_wave_scan_add(sg), sb = nrf_wave_scan_add(sb), sa = nrf_wave_scan_add(sa),
+    sd = nrf_wave_scan_add(sd);
+    if (lane == 63) {  // the inclusive sums end in lane 63
         const float bg = white_bkgd ? 1.f - sa : 0.f;                     // :259-261
         rgb_map[ray * 3 + 0] = sr + bg;
         rgb_map[ray * 3 + 1] = sg + bg;

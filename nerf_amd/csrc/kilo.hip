@@ -396,30 +396,15 @@ __global__ __launch_bounds__(256) void kilo_composite_kernel(const float4* __res
         const bool in = s < n;
         const float4 rv = in ? raw[base + s] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float ts = in ? t_start[base + s] : 0.f, te = in ? t_end[base + s] : 0.f;
-        const float alpha = in ? 1.f - expf(-fmaxf(rv.w, 0.f) * (te - ts)) : 0.f;  // volumn_renderer.py:99-100
-        float p = 1.f - alpha;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float t = __shfl_up(p, off);
-            if (lane >= off) p *= t;
-        }
-        float ex = __shfl_up(p, 1);
-        if (lane == 0) ex = 1.f;
-        const float T = carry * ex;
-        carry *= __shfl(p, 63);
-        const float w = T >= ert_eps ? T * alpha : 0.f;  // early ray termination: samples behind T < eps are dropped
-        sr += w / (1.f + expf(-rv.x));
-        sg += w / (1.f + expf(-rv.y));
-        sb += w / (1.f + expf(-rv.z));
+        const PackedChunk k = packed_chunk(rv, te - ts, in, carry);
+        const float w = k.T >= ert_eps ? k.T * k.alpha : 0.f;  // early ray termination: samples behind T < eps are dropped
+        sr += w * k.cr, sg += w * k.cg, sb += w * k.cb;
         sa += w;
         sd += w * 0.5f * (ts + te);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        sr += __shfl_xor(sr, off), sg += __shfl_xor(sg, off), sb += __shfl_xor(sb, off);
-        sa += __shfl_xor(sa, off), sd += __shfl_xor(sd, off);
-    }
-    if (lane == 0) {
+    sr = nrf_wave_scan_add(sr), sg = nrf_wave_scan_add(sg), sb = nrf_wave_scan_add(sb), sa = nrf_wave_scan_add(sa),
+    sd = nrf_wave_scan_add(sd);
+    if (lane == 63) {  // the inclusive sums end in lane 63
         const float bg = white_bkgd ? 1.f - sa : 0.f;  // volumn_renderer.py:116
         rgb_map[ray * 3] = sr + bg, rgb_map[ray * 3 + 1] = sg + bg, rgb_map[ray * 3 + 2] = sb + bg;
         depth_map[ray] = sd / fmaxf(sa, 1.1920929e-07f);

@@ -384,29 +384,13 @@ __global__ __launch_bounds__(256) void kilo_composite_bwd_kernel(const float4* _
         const bool in = s < n;
         const float4 rv = in ? raw[base + s] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float ts = in ? t_start[base + s] : 0.f, te = in ? t_end[base + s] : 0.f;
-        const float alpha = in ? 1.f - expf(-fmaxf(rv.w, 0.f) * (te - ts)) : 0.f;
-        float p = 1.f - alpha;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float t = __shfl_up(p, off);
-            if (lane >= off) p *= t;
-        }
-        float ex = __shfl_up(p, 1);
-        if (lane == 0) ex = 1.f;
-        const float T = carry * ex;
-        carry *= __shfl(p, 63);
-        const float w = T >= ert_eps ? T * alpha : 0.f;
-        sr += w / (1.f + expf(-rv.x));
-        sg += w / (1.f + expf(-rv.y));
-        sb += w / (1.f + expf(-rv.z));
+        const PackedChunk k = packed_chunk(rv, te - ts, in, carry);
+        const float w = k.T >= ert_eps ? k.T * k.alpha : 0.f;
+        sr += w * k.cr, sg += w * k.cg, sb += w * k.cb;
         sa += w;
         sd += w * 0.5f * (ts + te);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        sr += __shfl_xor(sr, off), sg += __shfl_xor(sg, off), sb += __shfl_xor(sb, off);
-        sa += __shfl_xor(sa, off), sd += __shfl_xor(sd, off);
-    }
+    sr = wave_total(sr), sg = wave_total(sg), sb = wave_total(sb), sa = wave_total(sa), sd = wave_total(sd);
     const float gr = g_rgb[ray * 3], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
     const float ga = g_acc ? g_acc[ray] : 0.f, gd = g_depth ? g_depth[ray] : 0.f;
     const float eps32 = 1.1920929e-07f;
@@ -425,29 +409,14 @@ __global__ __launch_bounds__(256) void kilo_composite_bwd_kernel(const float4* _
         const float4 rv = in ? raw[base + s] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float ts = in ? t_start[base + s] : 0.f, te = in ? t_end[base + s] : 0.f;
         const float delta = te - ts;
-        const float alpha = in ? 1.f - expf(-fmaxf(rv.w, 0.f) * delta) : 0.f;
-        float p = 1.f - alpha;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float t = __shfl_up(p, off);
-            if (lane >= off) p *= t;
-        }
-        float ex = __shfl_up(p, 1);
-        if (lane == 0) ex = 1.f;
-        const float T = carry * ex;
-        carry *= __shfl(p, 63);
+        const PackedChunk k = packed_chunk(rv, delta, in, carry);
+        const float alpha = k.alpha, T = k.T, cr = k.cr, cg = k.cg, cb = k.cb;
         const bool live = in && T >= ert_eps;
         const float w = live ? T * alpha : 0.f;
-        const float cr = 1.f / (1.f + expf(-rv.x)), cg = 1.f / (1.f + expf(-rv.y)), cb = 1.f / (1.f + expf(-rv.z));
         const float G = gr * cr + gg * cg + gb * cb + cst + dcoef * 0.5f * (ts + te);
-        float q = G * w;                      // inclusive prefix of G w over the ray
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float t = __shfl_up(q, off);
-            if (lane >= off) q += t;
-        }
+        const float q = nrf_wave_scan_add(G * w);  // inclusive prefix of G w over the ray
         const float incl = prefix + q;
-        prefix += __shfl(q, 63);
+        prefix += nrf_read_lane63(q);
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) {
             out.x = gr * w * cr * (1.f - cr);

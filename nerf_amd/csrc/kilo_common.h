@@ -88,4 +88,25 @@ __attribute__((unused)) inline KiloSortWs kilo_sort_ws(void* workspace, int64_t 
     return w;
 }
 
+// One 64-sample chunk of a packed ray: alpha, exclusive transmittance T (carried across chunks in `carry`) and
+// the sigmoid colours.  Shared by the forward and both passes of the backward compositing so that the three
+// agree bit for bit on which samples early termination keeps (T >= ert_eps).  Hardware exp / rcp and DPP scans
+// (composite.hip has the error budget); call with all 64 lanes active, `in` = lane has a sample.
+struct PackedChunk {
+    float alpha, T, cr, cg, cb;
+};
+__device__ __forceinline__ float packed_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ PackedChunk packed_chunk(float4 rv, float delta, bool in, float& carry) {
+    PackedChunk c;
+    c.alpha = in ? 1.f - packed_exp(-fmaxf(rv.w, 0.f) * delta) : 0.f;  // volumn_renderer.py:99-100
+    const float p = nrf_wave_scan_mul(1.f - c.alpha);
+    c.T = carry * nrf_lane_shr1(1.f, p);
+    carry *= nrf_read_lane63(p);
+    c.cr = __builtin_amdgcn_rcpf(1.f + packed_exp(-rv.x));
+    c.cg = __builtin_amdgcn_rcpf(1.f + packed_exp(-rv.y));
+    c.cb = __builtin_amdgcn_rcpf(1.f + packed_exp(-rv.z));
+    return c;
+}
+__device__ __forceinline__ float wave_total(float v) { return nrf_read_lane63(nrf_wave_scan_add(v)); }
+
 }  // namespace

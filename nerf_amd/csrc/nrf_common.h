@@ -22,6 +22,41 @@ static inline int nrf_launch_status() {
 static inline bool nrf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ------------------------------------------------------------------------------------
+// Wave64 scans on DPP (data-parallel primitives: the cross-lane operand is part of the VALU instruction, so a
+// scan step is one v_mul / v_add instead of ds_bpermute + s_waitcnt + select + op).  Lanes whose source lies
+// outside the row / bank keep `identity`.  Steps: Kogge-Stone inside each row of 16 (row_shr 1, 2, 4, 8), then
+// lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).
+// All 64 lanes must be active.
+// ------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float nrf_dpp(float identity, float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float nrf_wave_scan_mul(float p) {  // inclusive product over lanes 0..lane
+    p *= nrf_dpp<0x111>(1.f, p);
+    p *= nrf_dpp<0x112>(1.f, p);
+    p *= nrf_dpp<0x114>(1.f, p);
+    p *= nrf_dpp<0x118>(1.f, p);
+    p *= nrf_dpp<0x142, 0xa>(1.f, p);
+    p *= nrf_dpp<0x143, 0xc>(1.f, p);
+    return p;
+}
+__device__ __forceinline__ float nrf_wave_scan_add(float p) {  // inclusive sum; lane 63 holds the wave total
+    p += nrf_dpp<0x111>(0.f, p);
+    p += nrf_dpp<0x112>(0.f, p);
+    p += nrf_dpp<0x114>(0.f, p);
+    p += nrf_dpp<0x118>(0.f, p);
+    p += nrf_dpp<0x142, 0xa>(0.f, p);
+    p += nrf_dpp<0x143, 0xc>(0.f, p);
+    return p;
+}
+__device__ __forceinline__ float nrf_lane_shr1(float identity, float v) { return nrf_dpp<0x138>(identity, v); }  // wave_shr:1
+__device__ __forceinline__ float nrf_read_lane63(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// ------------------------------------------------------------------------------------
 // Packed ("streaming") layout of one 8x256 MLP, in floats.  See mlp_fp32.hip.
 //
 // The A-operand stream: one *step* = 256 floats = 1 KiB = one float4 per lane = the weight
