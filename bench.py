@@ -44,12 +44,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", default="render", choices=["render", "train", "kilo", "kilo_train", "testset"],
+    ap.add_argument("--mode", default="render", choices=["render", "train", "kilo", "kilo_train", "testset", "frame"],
                     help="render: BASELINE configs[1] (default, the headline metric); train: configs[2], "
                          "4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce; kilo: configs[3], KiloNeRF "
                          "800x800 frame with the sphere occupancy grid; kilo_train: KiloNeRF distillation step (SURVEY 8f rank 3); testset: configs[4], the 200-view test set "
                          "dealt round-robin over the ranks (strong scaling; a step = one pass over all views, a warm-up step = one "
-                         "view per rank; use with --dtype bf16)")
+                         "view per rank; use with --dtype bf16); frame: one view per step, its rays in contiguous slices over the ranks + one "
+                         "all_gather (strong scaling, the latency form of the metric)")
     ap.add_argument("--views", type=int, default=200, help="testset mode: number of views in the set")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="render mode only: fp32 = BASELINE configs[1] (the headline metric); bf16 = the bf16 MLP of "
@@ -383,6 +384,64 @@ def testset_bench(args, net, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def frame_bench(args, net, dev, rank, world, dist):
+    """Latency form of BASELINE configs[1] / the metric's "ms per 800x800 frame at 1/2/4/8 MI355X": ONE view per step,
+    its 640,000 rays split in contiguous slices over the ranks (Renderer.render_view_sharded), one all_gather of the
+    per-ray outputs so every rank ends the step holding the whole frame.  Strong scaling: the frame is fixed."""
+    from nerf_amd.camera import test_set_poses, focal_from_angle
+    from nerf_amd.config import default_cfg
+    from nerf_amd.renderer import Renderer
+    renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=args.dtype)
+    poses = test_set_poses(200)
+    focal = focal_from_angle(W)
+    R = H * W
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+
+    def step(k):
+        return renderer.render_view_sharded(poses[k % len(poses)], H, W, focal, rank, world, dev, gather=True, generator=gen)[0]
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        out = step(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = step(args.warmup + k)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out["fine_rgb_map"].shape == (R, 3) and torch.isfinite(out["fine_rgb_map"]).all()
+    if rank == 0:
+        bf16 = args.dtype == "bf16"
+        flop = float(R) * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
+        peak = (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS) * world
+        achieved = flop * args.steps / elapsed / 1e12
+        print(json.dumps({
+            "metric": "rays/sec (one 800x800 frame ray-sharded over the GPUs, 64 coarse + 128 fine samples/ray%s)" % (", bf16 MLP" if bf16 else ""),
+            "value": R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
+            "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
+            "config": {"workload": "BASELINE configs[1] latency form: one 800x800 view per step, rays in contiguous slices over "
+                                   "%d rank(s), outputs all-gathered on every rank, %s MLP" % (world, args.dtype),
+                       "rays_per_frame": R, "rays_per_rank": -(-R // world), "gather_bytes_per_ray": 36},
+            "roofline": {"kernel": "whole step (MLP FLOPs of the frame / wall time / (peak x ranks))", "bound": "mfma",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}}),
+            flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -423,6 +482,8 @@ def main():
         return train_bench(args, net, dev, rank, world, dist)
     if args.mode == "testset":
         return testset_bench(args, net, dev, rank, world, dist)
+    if args.mode == "frame":
+        return frame_bench(args, net, dev, rank, world, dist)
     renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=args.dtype)
     bf16 = args.dtype == "bf16"
     peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS

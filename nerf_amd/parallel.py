@@ -2,7 +2,7 @@
 
 Rays are independent, so inference needs no data-path collective: every rank generates its own
 rays from the pose and renders its slice with replicated weights.  The only communication is
-the optional assembly of one frame on every rank (one ``all_gather`` of 20 B per ray over
+the optional assembly of one frame on every rank (one ``all_gather`` of 36 B per ray, 20 B for the fine outputs alone, over
 RCCL / xGMI; ``gloo`` in the CPU tests).  The reference has no counterpart: it renders a view
 on a single device (``run.py:45-93``).
 """
@@ -56,18 +56,30 @@ def render_frame_sharded(render_rows, n_rays: int, rank: int, world: int, group=
     if not gather or world == 1:
         return local, (begin, end)
     import torch.distributed as dist
-    per = (n_rays + world - 1) // world          # all_gather wants equal shapes: pad to the largest slice
-    out = {}
-    for key, t in local.items():
-        flat = t.reshape(t.shape[0], -1)
-        pad = torch.zeros((per, flat.shape[1]), dtype=flat.dtype, device=flat.device)
-        pad[: flat.shape[0]] = flat
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-        pieces = []
-        for r in range(world):
-            b, e = shard_range(n_rays, r, world)
-            pieces.append(parts[r][: e - b])
-        full = torch.cat(pieces, 0)
-        out[key] = full.reshape((n_rays,) + tuple(t.shape[1:]))
+    # ONE collective per frame: the per-ray columns of every output (9 floats per ray for rgb x 2, depth x 2, acc) are
+    # packed side by side; all_gather wants equal shapes, so every rank pads to the largest slice.
+    per = (n_rays + world - 1) // world
+    keys = list(local)
+    cols = [local[k].reshape(local[k].shape[0], -1) for k in keys]
+    dtype, device = cols[0].dtype, cols[0].device
+    if any(c.dtype != dtype for c in cols):
+        raise TypeError("render_frame_sharded: all outputs must share one dtype to travel in one all_gather")
+    widths = [c.shape[1] for c in cols]
+    packed = torch.zeros((per, sum(widths)), dtype=dtype, device=device)
+    packed[: end - begin] = torch.cat(cols, 1)
+    shape = (world * per, packed.shape[1])                       # concatenated form: gloo accepts no stacked output
+    if packed.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal transport: stage through the host
+        host = torch.empty(shape, dtype=dtype)
+        dist.all_gather_into_tensor(host, packed.cpu(), group=group)
+        gathered = host.to(device)
+    else:
+        gathered = torch.empty(shape, dtype=dtype, device=device)
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+    gathered = gathered.view(world, per, -1)
+    rows = torch.cat([gathered[r, : shard_range(n_rays, r, world)[1] - shard_range(n_rays, r, world)[0]]
+                      for r in range(world)], 0)
+    out, c0 = {}, 0
+    for k, w in zip(keys, widths):
+        out[k] = rows[:, c0:c0 + w].reshape((n_rays,) + tuple(local[k].shape[1:]))
+        c0 += w
     return out, (begin, end)

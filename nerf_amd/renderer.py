@@ -345,3 +345,23 @@ class Renderer(nn.Module):
             # north-star aliases
             "rgb_map": f_rgb, "depth_map": f_depth, "acc_map": f_acc,
         }
+
+    def render_view_sharded(self, c2w, H: int, W: int, focal: float, rank: int, world: int, device, group=None,
+                            gather: bool = True, generator=None):
+        """ONE view over ``world`` GPUs (the north star's ray-tile sharding): this rank generates and
+        renders rays ``shard_range(H * W, rank, world)`` of the row-major pixel grid with its replica of the
+        weights, then (``gather``) one all_gather of 36 B per ray assembles the five per-ray outputs on every rank.
+        Returns (dict, (first_ray, end_ray)).  The reference renders a view on one device (run.py:45-93)."""
+        from .parallel import render_frame_sharded
+
+        def rows(first, count):
+            rays_o, rays_d = ops.raygen(c2w, H, W, focal, device, first_ray=first, n_rays=count)
+            u = torch.rand((count, self.N_importance), device=device, generator=generator)
+            u2 = torch.rand((count, self.N_importance), device=device, generator=generator)
+            out = self.render_rays(rays_o, rays_d, u, u2)
+            return {k: out[k] for k in ("coarse_rgb_map", "coarse_depth_map", "fine_rgb_map", "fine_depth_map", "alpha_map")}
+
+        with torch.no_grad():
+            out, span = render_frame_sharded(rows, H * W, rank, world, group=group, gather=gather)
+        out.update(rgb_map=out["fine_rgb_map"], depth_map=out["fine_depth_map"], acc_map=out["alpha_map"])
+        return out, span

@@ -130,3 +130,29 @@ def test_kilonerf_full_frame_slices(dev):
         for k in ("rgb_map", "depth_map", "alpha_map"):
             assert torch.equal(part[k][0], whole[k][0, sl]), k
     assert total == n_whole
+
+
+def test_sharded_view_slices_reassemble(frame, dev):
+    """Renderer.render_view_sharded on world = 1 (no process group) equals the plain frame for the same uniforms'
+    generator; and rank slices rendered without the gather are the matching slices of the ray-generated frame."""
+    from nerf_amd import ops
+    from nerf_amd.camera import focal_from_angle, test_set_poses
+    from nerf_amd.parallel import shard_range
+    r = frame[0]
+    pose, focal = test_set_poses(200)[3], focal_from_angle(W)
+    g = torch.Generator(device=dev).manual_seed(11)
+    whole, span = r.render_view_sharded(pose, H, W, focal, 0, 1, dev, generator=g)
+    assert span == (0, H * W) and whole["rgb_map"].shape == (H * W, 3)
+    o, d = ops.raygen(pose, H, W, focal, dev)
+    for rank in (0, 3):
+        b, e = shard_range(H * W, rank, 4)
+        g = torch.Generator(device=dev).manual_seed(100 + rank)
+        part, sp = r.render_view_sharded(pose, H, W, focal, rank, 4, dev, gather=False, generator=g)
+        assert sp == (b, e)
+        g = torch.Generator(device=dev).manual_seed(100 + rank)
+        u = torch.rand((e - b, 128), device=dev, generator=g)
+        u2 = torch.rand((e - b, 128), device=dev, generator=g)
+        with torch.no_grad():
+            ref = r.render_rays(o[b:e].contiguous(), d[b:e].contiguous(), u, u2)
+        for k in KEYS:
+            assert torch.equal(part[k], ref[k]), k

@@ -104,3 +104,8 @@ def test_allreduce_gradients_without_process_group_is_identity():
     from nerf_amd.parallel import allreduce_gradients
     g = torch.arange(5, dtype=torch.float32)
     assert allreduce_gradients(g) == 1.0 and torch.equal(g, torch.arange(5, dtype=torch.float32))
+
+
+def test_frame_assembly_single_rank_passthrough():
+    out, span = render_frame_sharded(_fake_render, 10, 0, 1)
+    assert span == (0, 10) and torch.equal(out["fine_depth_map"], _fake_render(0, 10)["fine_depth_map"])
