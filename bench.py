@@ -73,6 +73,15 @@ def recorded_traffic():
         return None
 
 
+def recorded_composite_traffic():
+    """Same for the fine compositing launch (profiles/r01_composite_traffic_pmc.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_composite_traffic_pmc.json")) as f:
+            return float(json.load(f)["traffic_bytes_fine_composite"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds: float):
     """Oracle render of 1024-ray slices of the bench view until ~`seconds` of CPU time."""
     from oracle import nerf_oracle as O
@@ -561,7 +570,8 @@ def main():
                          "ms_coarse_launch": ms_mlp_c, "ms_fine_launch": ms_mlp_f},
             "roofline_composite": {"kernel": "composite_kernel<3> (fine pass)", "bound": "hbm",
                                    "achieved": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": ms_cmp_f,
+                                   "frac": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": recorded_composite_traffic(), "ms_per_launch": ms_cmp_f,
                                    "bytes_per_launch": cmp_bytes},
             "stage_ms": {"mlp_coarse": ms_mlp_c, "composite_coarse": ms_cmp_c, "sample_fine": ms_smp,
                          "mlp_fine": ms_mlp_f, "composite_fine": ms_cmp_f},
