@@ -197,7 +197,10 @@ int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host,
  * to nerfacc (absent, unpinned).  This library's own rule: intervals [t0 + k*step, min(t0 + (k+1)*step, t1)) over
  * the ray/box overlap clipped to [near, far], kept when the occupancy voxel (uint8 grid, (rx,ry,rz) C order) at the
  * interval mid-point is non-zero; w_i = T_i * alpha_i while T_i >= ert_eps; depth = sum w t_mid / max(acc, eps). */
-int64_t nrf_kilo_march_workspace_bytes(int64_t n_rays);
+/* Two passes with one host read of `total` between them.  The workspace holds the scan's block sums and, from
+ * pass 1, one 64-bit keep mask per ray and 64-step chunk; pass 2 given `counts` and that workspace writes the kept
+ * samples from the masks (no second walk of the grid); with workspace == NULL it walks the grid again. */
+int64_t nrf_kilo_march_workspace_bytes(int64_t n_rays, float t_near, float t_far, float step);
 int nrf_kilo_march_count(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
                          const int* occ_res_host, const float* aabb_host, float t_near, float t_far, float step,
                          int32_t* counts, int32_t* offsets, int64_t* total, void* workspace, int64_t workspace_bytes,
@@ -205,7 +208,7 @@ int nrf_kilo_march_count(const float* rays_o, const float* rays_d, int64_t n_ray
 int nrf_kilo_march_write(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
                          const int* occ_res_host, const float* aabb_host, float t_near, float t_far, float step,
                          const int32_t* offsets, float* pts, int32_t* ray_idx, float* t_start, float* t_end,
-                         nrf_stream_t stream);
+                         const int32_t* counts, const void* workspace, int64_t workspace_bytes, nrf_stream_t stream);
 int nrf_kilo_composite(const float* raw, const float* t_start, const float* t_end, const int32_t* offsets,
                        const int32_t* counts, int64_t n_rays, float ert_eps, int white_bkgd, float* rgb_map,
                        float* depth_map, float* acc_map, nrf_stream_t stream);

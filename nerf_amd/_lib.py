@@ -116,9 +116,9 @@ def lib() -> C.CDLL:
     L.nrf_kilo_forward_workspace_bytes.argtypes = [I64, INT]
     L.nrf_kilo_forward.argtypes = [P, INT, P, P, P, P, P, I64, P, P, I64, P]
     L.nrf_kilo_march_workspace_bytes.restype = I64
-    L.nrf_kilo_march_workspace_bytes.argtypes = [I64]
+    L.nrf_kilo_march_workspace_bytes.argtypes = [I64, F, F, F]
     L.nrf_kilo_march_count.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, I64, P]
-    L.nrf_kilo_march_write.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, P, P]
+    L.nrf_kilo_march_write.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, P, P, P, I64, P]
     L.nrf_kilo_composite.argtypes = [P, P, P, P, P, I64, F, INT, P, P, P, P]
     L.nrf_kilo_packed_bwd_floats.restype = I64
     L.nrf_kilo_packed_bwd_floats.argtypes = [INT]

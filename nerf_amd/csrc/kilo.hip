@@ -17,6 +17,8 @@
 //   * packed compositing is the same wave scan as composite.hip over a ragged segment.
 // nerfacc is absent and unpinned: the sampling / termination / packed-rendering rules below
 // are this repo's own specification, checked against oracle/kilo_oracle.py.
+#include <cmath>
+
 #include "kilo_common.h"
 
 namespace {
@@ -339,7 +341,8 @@ __global__ __launch_bounds__(256) void kilo_march_kernel(March m, const float* _
                                                          const unsigned char* __restrict__ occ, int* __restrict__ counts,
                                                          const int* __restrict__ offsets, float* __restrict__ pts,
                                                          int* __restrict__ ray_idx, float* __restrict__ t_start,
-                                                         float* __restrict__ t_end) {
+                                                         float* __restrict__ t_end,
+                                                         unsigned long long* __restrict__ masks, int max_chunks) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256) void kilo_march_kernel(March m, const float* _
     const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
     float t0, t1;
     int count = 0;
+    unsigned long long held = 0;
     if (ray_box(m, o, d, t0, t1)) {
         const int nsteps = int(ceilf((t1 - t0) / m.step));
         const int base = WRITE ? offsets[ray] : 0;
@@ -367,6 +371,13 @@ __global__ __launch_bounds__(256) void kilo_march_kernel(March m, const float* _
                 keep = occ[(int64_t(v[0]) * m.g.res[1] + v[1]) * m.g.res[2] + v[2]] != 0;
             }
             const unsigned long long mask = __ballot(keep);
+            if (!WRITE && masks) {   // lane c & 63 holds chunk c's keep mask; flushed 64 chunks (or the tail) at a time
+                const int c = k0 >> 6;
+                if (lane == (c & 63)) held = mask;
+                if ((c & 63) == 63 || k0 + 64 >= nsteps) {
+                    if (lane <= (c & 63) && (c & ~63) + lane < max_chunks) masks[ray * max_chunks + (c & ~63) + lane] = held;
+                }
+            }
             if (WRITE && keep) {
                 const int pos = base + count + __popcll(mask & ((1ull << lane) - 1ull));
                 pts[int64_t(pos) * 3] = p[0], pts[int64_t(pos) * 3 + 1] = p[1], pts[int64_t(pos) * 3 + 2] = p[2];
@@ -377,6 +388,52 @@ __global__ __launch_bounds__(256) void kilo_march_kernel(March m, const float* _
         }
     }
     if (!WRITE && lane == 0) counts[ray] = count;
+}
+
+// Pass 2 when pass 1 kept its ballots: no occupancy lookups, rays without samples leave at once and empty chunks
+// are skipped, so only kept samples cost arithmetic.  Same expressions for ts / te / p as kilo_march_kernel: the
+// two write paths are bit-identical (tests/test_gpu_kilo.py).
+__global__ __launch_bounds__(256) void kilo_march_write_masks_kernel(March m, const float* __restrict__ rays_o,
+                                                                     const float* __restrict__ rays_d, int64_t n_rays,
+                                                                     const int* __restrict__ counts,
+                                                                     const int* __restrict__ offsets,
+                                                                     const unsigned long long* __restrict__ masks,
+                                                                     int max_chunks, float* __restrict__ pts,
+                                                                     int* __restrict__ ray_idx, float* __restrict__ t_start,
+                                                                     float* __restrict__ t_end) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int n = counts[ray];
+    if (n == 0) return;
+    const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2]};
+    const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
+    float t0, t1;
+    if (!ray_box(m, o, d, t0, t1)) return;
+    const int nsteps = int(ceilf((t1 - t0) / m.step));
+    const int nchunks = min((nsteps + 63) >> 6, max_chunks);
+    int pos0 = offsets[ray];
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const unsigned long long mine = c0 + lane < nchunks ? masks[ray * max_chunks + c0 + lane] : 0ull;
+        unsigned long long nonempty = __ballot(mine != 0ull);
+        while (nonempty) {
+            const int cl = __ffsll((long long)nonempty) - 1;
+            nonempty &= nonempty - 1;
+            const unsigned long long mask = (unsigned long long)__shfl((long long)mine, cl);
+            if ((mask >> lane) & 1ull) {
+                const int k = (c0 + cl) * 64 + lane;
+                const float ts = t0 + float(k) * m.step;
+                const float te = fminf(ts + m.step, t1);
+                const float tm = 0.5f * (ts + te);
+                const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
+                pts[int64_t(pos) * 3] = o[0] + d[0] * tm, pts[int64_t(pos) * 3 + 1] = o[1] + d[1] * tm;
+                pts[int64_t(pos) * 3 + 2] = o[2] + d[2] * tm;
+                ray_idx[pos] = int(ray);
+                t_start[pos] = ts, t_end[pos] = te;
+            }
+            pos0 += __popcll(mask);
+        }
+    }
 }
 
 // ---- packed compositing with early ray termination (own specification) -----------------------
@@ -498,12 +555,24 @@ static int check_march(const float* rays_o, const float* rays_d, const unsigned 
     return NRF_OK;
 }
 
-// scan workspace: ceil(n/1024) ints
-NRF_EXPORT int64_t nrf_kilo_march_workspace_bytes(int64_t n_rays) {
-    return n_rays < 0 ? NRF_ERR_SHAPE : a256(((n_rays + kScanBlock - 1) / kScanBlock + 1) * 4);
+// workspace: scan block sums (ceil(n/1024) + 1 ints), then the keep masks of pass 1 (one uint64 per ray and 64-step
+// chunk; ceil((far - near) / step) steps at most, one chunk of slack for the rounding of the step count)
+static int march_max_chunks(float t_near, float t_far, float step) {
+    if (!(step > 0.f) || !(t_far > t_near)) return -1;
+    const double steps = std::ceil((double(t_far) - double(t_near)) / double(step));
+    if (!(steps < double(1 << 22))) return -1;
+    return int(steps) / 64 + 2;
+}
+static int64_t march_scan_bytes(int64_t n_rays) { return a256(((n_rays + kScanBlock - 1) / kScanBlock + 1) * 4); }
+
+NRF_EXPORT int64_t nrf_kilo_march_workspace_bytes(int64_t n_rays, float t_near, float t_far, float step) {
+    const int mc = march_max_chunks(t_near, t_far, step);
+    if (n_rays < 0 || mc < 0) return NRF_ERR_SHAPE;
+    return march_scan_bytes(n_rays) + a256(n_rays * mc * 8);
 }
 
-// Pass 1: per-ray sample counts, their exclusive prefix (offsets) and the total (device int64).
+// Pass 1: per-ray sample counts, their exclusive prefix (offsets) and the total (device int64); the per-chunk keep
+// masks stay in the workspace for pass 2.
 NRF_EXPORT int nrf_kilo_march_count(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
                                     const int* occ_res_host, const float* aabb_host, float t_near, float t_far,
                                     float step, int32_t* counts, int32_t* offsets, int64_t* total, void* workspace,
@@ -512,14 +581,17 @@ NRF_EXPORT int nrf_kilo_march_count(const float* rays_o, const float* rays_d, in
     if (n_rays == 0) return NRF_OK;
     if (int st = check_march(rays_o, rays_d, occ, aabb_host, occ_res_host, t_near, t_far, step)) return st;
     if (!counts || !offsets || !total || !workspace) return NRF_ERR_NULL;
-    if (workspace_bytes < nrf_kilo_march_workspace_bytes(n_rays)) return NRF_ERR_WORKSPACE;
+    const int mc = march_max_chunks(t_near, t_far, step);
+    if (mc < 0) return NRF_ERR_SHAPE;
+    if (workspace_bytes < nrf_kilo_march_workspace_bytes(n_rays, t_near, t_far, step)) return NRF_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     March m{make_grid(aabb_host, occ_res_host), t_near, t_far, step};
     const int64_t blocks = (n_rays + 3) / 4;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    auto* masks = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + march_scan_bytes(n_rays));
     nrf_launch_begin();
     kilo_march_kernel<false><<<dim3((unsigned)blocks), 256, 0, stream>>>(m, rays_o, rays_d, n_rays, occ, counts, nullptr,
-                                                                         nullptr, nullptr, nullptr, nullptr);
+                                                                         nullptr, nullptr, nullptr, nullptr, masks, mc);
     int* sums = static_cast<int*>(workspace);
     const int nb = int((n_rays + kScanBlock - 1) / kScanBlock);
     scan_block_kernel<<<nb, kScanBlock, 0, stream>>>(counts, n_rays, offsets, sums);
@@ -528,11 +600,14 @@ NRF_EXPORT int nrf_kilo_march_count(const float* rays_o, const float* rays_d, in
     return nrf_launch_status();
 }
 
-// Pass 2: write the packed samples (mid-point positions, ray index, interval) in ray order.
+// Pass 2: write the packed samples (mid-point positions, ray index, interval) in ray order.  With `counts` and the
+// workspace pass 1 filled (same rays, same grid, same stream order) the kept steps come from its masks; with
+// workspace == NULL the occupancy grid is walked again.
 NRF_EXPORT int nrf_kilo_march_write(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
                                     const int* occ_res_host, const float* aabb_host, float t_near, float t_far,
                                     float step, const int32_t* offsets, float* pts, int32_t* ray_idx, float* t_start,
-                                    float* t_end, nrf_stream_t stream_) {
+                                    float* t_end, const int32_t* counts, const void* workspace, int64_t workspace_bytes,
+                                    nrf_stream_t stream_) {
     if (n_rays < 0) return NRF_ERR_SHAPE;
     if (n_rays == 0) return NRF_OK;
     if (int st = check_march(rays_o, rays_d, occ, aabb_host, occ_res_host, t_near, t_far, step)) return st;
@@ -540,9 +615,21 @@ NRF_EXPORT int nrf_kilo_march_write(const float* rays_o, const float* rays_d, in
     March m{make_grid(aabb_host, occ_res_host), t_near, t_far, step};
     const int64_t blocks = (n_rays + 3) / 4;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (workspace) {
+        if (!counts) return NRF_ERR_NULL;
+        const int mc = march_max_chunks(t_near, t_far, step);
+        if (mc < 0) return NRF_ERR_SHAPE;
+        if (workspace_bytes < nrf_kilo_march_workspace_bytes(n_rays, t_near, t_far, step)) return NRF_ERR_WORKSPACE;
+        auto* masks = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(workspace) + march_scan_bytes(n_rays));
+        nrf_launch_begin();
+        kilo_march_write_masks_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(m, rays_o, rays_d, n_rays, counts, offsets,
+                                                                                   masks, mc, pts, ray_idx, t_start, t_end);
+        return nrf_launch_status();
+    }
     nrf_launch_begin();
-    kilo_march_kernel<true><<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream_)>>>(
-        m, rays_o, rays_d, n_rays, occ, nullptr, offsets, pts, ray_idx, t_start, t_end);
+    kilo_march_kernel<true><<<dim3((unsigned)blocks), 256, 0, stream>>>(m, rays_o, rays_d, n_rays, occ, nullptr, offsets, pts,
+                                                                        ray_idx, t_start, t_end, nullptr, 0);
     return nrf_launch_status();
 }
 

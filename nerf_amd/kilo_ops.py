@@ -148,9 +148,11 @@ def l2_reg(param: torch.Tensor, coeff: float, grad_accum: torch.Tensor | None, l
               "nrf_l2_reg")
 
 
-def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: float, step: float):
+def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: float, step: float,
+               reuse_masks: bool = True):
     """Occupancy-grid marching.  Returns (pts (N,3), ray_idx (N,), t_start (N,), t_end (N,),
-    offsets (R,), counts (R,)); one host sync to learn N between the count and the write pass."""
+    offsets (R,), counts (R,)); one host sync to learn N between the count and the write pass.  ``reuse_masks``:
+    the write pass takes the kept steps from the count pass's ballots instead of walking the grid again (same bits)."""
     rays_o, rays_d = _f32(rays_o, "rays_o").reshape(-1, 3), _f32(rays_d, "rays_d").reshape(-1, 3)
     if occ.dtype != torch.uint8 or occ.ndim != 3 or not occ.is_cuda:
         raise NrfError("occ: expected a 3-D uint8 cuda tensor")
@@ -161,7 +163,10 @@ def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: fl
     counts = torch.zeros(R, dtype=torch.int32, device=dev)
     offsets = torch.zeros(R, dtype=torch.int32, device=dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
-    ws = torch.empty(max(int(lib().nrf_kilo_march_workspace_bytes(R)), 256), dtype=torch.uint8, device=dev)
+    need = int(lib().nrf_kilo_march_workspace_bytes(R, float(t_near), float(t_far), float(step)))
+    if need < 0:
+        check(need, "nrf_kilo_march_workspace_bytes")
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(lib().nrf_kilo_march_count(_ptr(rays_o), _ptr(rays_d), R, _ptr(occ), pr, pa, float(t_near), float(t_far),
                                          float(step), _ptr(counts), _ptr(offsets), _ptr(total), _ptr(ws), ws.numel(),
@@ -174,7 +179,9 @@ def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: fl
         if n:
             check(lib().nrf_kilo_march_write(_ptr(rays_o), _ptr(rays_d), R, _ptr(occ), pr, pa, float(t_near),
                                              float(t_far), float(step), _ptr(offsets), _ptr(pts), _ptr(ray_idx),
-                                             _ptr(t_start), _ptr(t_end), _stream(rays_o)), "nrf_kilo_march_write")
+                                             _ptr(t_start), _ptr(t_end), _ptr(counts),
+                                             _ptr(ws) if reuse_masks else None, ws.numel() if reuse_masks else 0,
+                                             _stream(rays_o)), "nrf_kilo_march_write")
     return pts, ray_idx, t_start, t_end, offsets, counts
 
 

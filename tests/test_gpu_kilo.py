@@ -128,6 +128,24 @@ def test_march_bit_exact_vs_oracle(dev):
     assert int(ref[5].sum()) > 10000
     for nm, a, b in zip(names, out, ref):
         assert np.array_equal(a.cpu().numpy(), b), nm
+    # the write pass that walks the grid again (no masks handed over) gives the same bits
+    again = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), _t(occ, dev), AABB, 2.0, 6.0, 0.005, reuse_masks=False)
+    for nm, a, b in zip(names, again, out):
+        assert torch.equal(a, b), nm
+
+
+@pytest.mark.parametrize("step", [0.0007, 0.05, 3.0])
+def test_march_mask_handover_other_step_sizes(dev, step):
+    """More than 64 chunks per ray (step 7e-4: 5715 steps), a few steps per ray, and a single step."""
+    from nerf_amd import kilo_ops
+    from oracle import kilo_oracle as K
+    occ = _sphere_occ(32, 0.9)
+    o, d = _camera_rays(12, seed=5)
+    ref = K.march(o, d, occ, AABB[:3], AABB[3:], 2.0, 6.0, step)
+    for reuse in (True, False):
+        out = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), _t(occ, dev), AABB, 2.0, 6.0, step, reuse_masks=reuse)
+        for nm, a, b in zip(["pts", "ray_idx", "t_start", "t_end", "offsets", "counts"], out, ref):
+            assert np.array_equal(a.cpu().numpy(), b), (nm, reuse)
 
 
 def test_march_empty_grid_and_no_rays(dev):
