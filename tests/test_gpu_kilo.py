@@ -134,16 +134,19 @@ def test_march_bit_exact_vs_oracle(dev):
         assert torch.equal(a, b), nm
 
 
-@pytest.mark.parametrize("step", [0.0007, 0.05, 3.0])
-def test_march_mask_handover_other_step_sizes(dev, step):
-    """More than 64 chunks per ray (step 7e-4: 5715 steps), a few steps per ray, and a single step."""
+@pytest.mark.parametrize("step,box", [(0.0007, AABB), (0.05, AABB), (3.0, AABB),
+                                      (0.004, [-1.3, -0.9, -1.0, 1.1, 1.2, 0.7]), (0.01, [-2.0, -0.5, -1.0, 2.0, 0.5, 1.0])])
+def test_march_mask_handover_other_step_sizes(dev, step, box):
+    """More than 64 chunks per ray (step 7e-4: 5715 steps), a few steps per ray, a single step; boxes whose edges
+    are not powers of two (the kernel then divides instead of multiplying by the exact reciprocal) or differ."""
     from nerf_amd import kilo_ops
     from oracle import kilo_oracle as K
     occ = _sphere_occ(32, 0.9)
     o, d = _camera_rays(12, seed=5)
-    ref = K.march(o, d, occ, AABB[:3], AABB[3:], 2.0, 6.0, step)
+    ref = K.march(o, d, occ, box[:3], box[3:], 2.0, 6.0, step)
+    assert int(ref[5].sum()) > 0
     for reuse in (True, False):
-        out = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), _t(occ, dev), AABB, 2.0, 6.0, step, reuse_masks=reuse)
+        out = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), _t(occ, dev), box, 2.0, 6.0, step, reuse_masks=reuse)
         for nm, a, b in zip(["pts", "ray_idx", "t_start", "t_end", "offsets", "counts"], out, ref):
             assert np.array_equal(a.cpu().numpy(), b), (nm, reuse)
 
