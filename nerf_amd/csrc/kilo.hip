@@ -86,14 +86,20 @@ __device__ __forceinline__ int route_cell(const Grid& g, float x, float y, float
     return (idx[0] * g.res[1] + idx[1]) * g.res[2] + idx[2];  // :251-253
 }
 
-__global__ void kilo_route_kernel(Grid g, const float* __restrict__ pts, int64_t n, int* __restrict__ cell,
-                                  int* __restrict__ hist) {
+// Consecutive points are consecutive samples of neighbouring rays, so a CONTIGUOUS chunk of kSortChunk points
+// touches only a dozen cells: a block owns one chunk, histograms it in LDS and sends one global atomic per touched
+// cell (a grid-stride block would see every occupied cell and send ~900).
+constexpr int kSortChunk = 4096;
+__global__ __launch_bounds__(256) void kilo_route_kernel(Grid g, const float* __restrict__ pts, int64_t n,
+                                                         int* __restrict__ cell, int* __restrict__ hist) {
     extern __shared__ int s_hist[];
     const int ncell = g.res[0] * g.res[1] * g.res[2];
     if (hist)
         for (int i = threadIdx.x; i < ncell; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t begin = int64_t(blockIdx.x) * kSortChunk;
+    const int64_t end = begin + kSortChunk < n ? begin + kSortChunk : n;
+    for (int64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
         const int c = route_cell(g, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
         cell[i] = c;
         if (hist) atomicAdd(&s_hist[c], 1);
@@ -138,29 +144,49 @@ __global__ void kilo_cell_scan_kernel(const int* __restrict__ hist, int ncell, i
     if (tid == 1023) seg_start[ncell] = s_a[1023], job_prefix[ncell] = s_b[1023];
 }
 
-// Counting-sort scatter.  Consecutive points are consecutive samples of one ray and stay in a cell for ~25
-// steps, so per-point atomics on cursor[cell] collide 64-wide; instead each run of equal cells inside a
-// wavefront takes ONE atomic for the whole run (its head lane) and the lanes of the run fan out behind it.
-__global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict__ cell, int64_t n, int* __restrict__ cursor,
-                                                           int* __restrict__ perm) {
+// Counting-sort scatter, same chunking.  Per-point atomics on cursor[cell] would collide 64-wide and a return-value
+// atomic on a device-scope counter is the expensive operation here (1.1 M of them at one per run of equal cells per
+// wavefront: 0.42 ms per frame).  A block (1) counts its chunk per cell in LDS -- one LDS atomic per run: consecutive
+// points stay in a cell for ~25 steps, the head lane of a run adds the run's length --, (2) reserves the chunk's
+// range of every touched cell with ONE global atomic each (~12 per 4096 points) and (3) hands out positions from
+// the LDS cursors, again one LDS atomic per run.  The order inside a cell is whatever order the atomics land in,
+// as before; the cells are held in registers between (1) and (3).
+__global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict__ cell, int64_t n, int ncell,
+                                                           int* __restrict__ cursor, int* __restrict__ perm) {
+    extern __shared__ int s_cur[];
+    constexpr int kRounds = kSortChunk / 256;
     const int lane = threadIdx.x & 63;
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    const int64_t rounds = (n + stride - 1) / stride;  // every lane runs every round: shuffles need full waves
-    for (int64_t k = 0; k < rounds; ++k) {
-        const int64_t i = k * stride + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-        const bool in = i < n;
-        const int c = in ? cell[i] : -1;
-        const int prev = __shfl_up(c, 1);
-        const bool head = lane == 0 || c != prev;
+    for (int i = threadIdx.x; i < ncell; i += 256) s_cur[i] = 0;
+    __syncthreads();
+    const int64_t begin = int64_t(blockIdx.x) * kSortChunk;
+    int c[kRounds], head_lane[kRounds], run_len[kRounds];
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {  // every lane runs every round: shuffles and ballots need full waves
+        const int64_t i = begin + k * 256 + threadIdx.x;
+        c[k] = i < n ? cell[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+        const int prev = __shfl_up(c[k], 1);
+        const bool head = lane == 0 || c[k] != prev;
         const unsigned long long heads = __ballot(head);
         const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-        const int head_lane = 63 - __clzll(upto);                       // last head at or before this lane
+        head_lane[k] = 63 - __clzll(upto);                                   // last head at or before this lane
         const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
-        const int next_head = after ? __ffsll((long long)after) - 1 : 64;  // first head after this lane
+        const int next_head = after ? __ffsll((long long)after) - 1 : 64;    // first head after this lane
+        run_len[k] = head && c[k] >= 0 ? next_head - lane : 0;               // > 0 on the head lane of a run
+        if (run_len[k]) atomicAdd(&s_cur[c[k]], run_len[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncell; i += 256)
+        if (s_cur[i]) s_cur[i] = atomicAdd(&cursor[i], s_cur[i]);            // count -> first position of the chunk's range
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
         int base = 0;
-        if (head && in) base = atomicAdd(&cursor[c], next_head - lane);
-        base = __shfl(base, head_lane);
-        if (in) perm[base + (lane - head_lane)] = int(i);
+        if (run_len[k]) base = atomicAdd(&s_cur[c[k]], run_len[k]);
+        base = __shfl(base, head_lane[k]);
+        if (c[k] >= 0) perm[base + (lane - head_lane[k])] = int(begin + k * 256 + threadIdx.x);
     }
 }
 
@@ -500,10 +526,10 @@ NRF_EXPORT int nrf_kilo_route(const float* pts, int64_t n, const float* aabb_hos
     if (!pts || !aabb_host || !res_host || !cell) return NRF_ERR_NULL;
     const Grid g = make_grid(aabb_host, res_host);
     if (g.res[0] <= 0 || g.res[1] <= 0 || g.res[2] <= 0) return NRF_ERR_SHAPE;
-    const int64_t blocks = (n + 255) / 256;
+    const int64_t blocks = (n + kSortChunk - 1) / kSortChunk;   // one contiguous chunk per block
+    if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
     nrf_launch_begin();
-    kilo_route_kernel<<<dim3(unsigned(blocks < 4096 ? blocks : 4096)), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        g, pts, n, cell, nullptr);
+    kilo_route_kernel<<<dim3(unsigned(blocks)), 256, 0, static_cast<hipStream_t>(stream)>>>(g, pts, n, cell, nullptr);
     return nrf_launch_status();
 }
 
@@ -534,14 +560,13 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
     if (cus <= 0) cus = 256;
     nrf_launch_begin();
     (void)hipMemsetAsync(hist, 0, size_t(num_cells + 1) * 4, stream);
-    const int64_t blocks = (n_points + 255) / 256;
-    const unsigned rb = unsigned(blocks < 2048 ? blocks : 2048);
+    const unsigned rb = unsigned((n_points + kSortChunk - 1) / kSortChunk);   // n_points <= 2^28: at most 65536 blocks
     kilo_route_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(g, pts, n_points, cell, hist);
     // tiles of one cell per weight load: up to kJobTiles, fewer for small batches so that every wavefront gets jobs
     int64_t jt = (n_points + 32 * 4 * int64_t(cus) * 4 - 1) / (32 * 4 * int64_t(cus) * 4);
     const int job_tiles = int(jt < 4 ? 4 : jt > kJobTiles ? kJobTiles : jt);
     kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, job_tiles, seg_start, cursor, job_prefix);
-    kilo_scatter_kernel<<<dim3(rb), 256, 0, stream>>>(cell, n_points, cursor, perm);
+    kilo_scatter_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(cell, n_points, num_cells, cursor, perm);
     if (dir_index)
         kilo_mlp_kernel<true><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
                                                                        dirs, dir_index, reinterpret_cast<float4*>(raw));
