@@ -193,19 +193,21 @@ __global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict
 // Persistent waves over jobs; job = up to kJobTiles 32-point tiles of one cell's sorted segment.
 //
 // What bounds it (measured): on gfx950 the f32 MFMA runs at the vector-ALU rate (64 cycles per
-// 32x32x2; 157 TF is also the VALU peak) and VALU work does not hide under it: ablations show tile time = its 96
-// MFMAs (6.1k cycles) PLUS its VALU instructions (~1200 with every sin/cos through the polynomial, ~4.7 cycles
-// each; encode_pe_doubling takes the odd octaves by a double-angle step and removes ~260 of them).
-// Hand-interleaving the next tile's encoding into the MFMA gaps, and two waves per SIMD, both measured no faster,
-// so this is the plain form: one wave per SIMD, the cell's whole weight set in registers for the job (24 float4 of
-// matrix operands, biases as accumulator initialisers, head rows), gathers prefetched three tiles ahead.
+// 32x32x2; 157 TF is also the VALU peak) and inside ONE wave VALU work does not hide under it: tile time = its 96
+// MFMAs (6.1k cycles) PLUS its ~540 VALU instructions (~4.7 cycles each; encode_pe_doubling already halved the
+// sin/cos share).  Across waves the two pipes do overlap, so the kernel runs TWO waves per SIMD: the cell's matrix
+// operands stay in registers for the job (24 float4), biases and head rows are re-read per tile from a wave-private
+// LDS slice (as 128 more live registers they cost the second wave and, before that, 69 AGPR read-backs per tile),
+// gathers are prefetched three tiles ahead.  History: one wave per SIMD with everything in registers 3.99 ms,
+// small section in LDS 3.85 ms, two waves per SIMD 3.4 ms per 27.4 M-sample frame.
 template <bool INDEXED>  // directions gathered through dir_index (one per ray) or given per point
-__global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
+__global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
                                                           const int* __restrict__ seg_start,
                                                           const int* __restrict__ job_prefix,
                                                           const int* __restrict__ perm, const float* __restrict__ pts,
                                                           const float* __restrict__ dirs,
                                                           const int* __restrict__ dir_index, float4* __restrict__ raw) {
+    __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -225,15 +227,19 @@ __global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restric
         float4 w[kKiloSteps];
 #pragma unroll
         for (int s = 0; s < kKiloSteps; ++s) w[s] = reinterpret_cast<const float4*>(cw)[s * 64 + lane];
-        const float* sm = cw + kKiloSteps * 256;
-        f32x16 bias[4];
-#pragma unroll
-        for (int l = 0; l < 4; ++l) bias[l] = *reinterpret_cast<const f32x16*>(sm + kKOffBias + l * 32 + h * 16);
-        const f32x16 sw = *reinterpret_cast<const f32x16*>(sm + kKOffSigW + h * 16);
-        f32x16 rw[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) rw[c] = *reinterpret_cast<const f32x16*>(sm + kKOffRgbW + c * 32 + h * 16);
-        const float sb = sm[kKOffSigB], rb0 = sm[kKOffRgbB], rb1 = sm[kKOffRgbB + 1], rb2 = sm[kKOffRgbB + 2];
+        // biases and head rows (288 floats) go to this wave's LDS slice and are re-read per tile: as 128 more live
+        // registers they pushed the kernel past 256 VGPRs, every layer's output landed in AGPRs and came back one
+        // v_accvgpr_read at a time (69 per tile).  Wave-private region: no barrier, the wave's own LDS order suffices.
+        float* sm_job = s_small[threadIdx.x >> 6];
+        {
+            const float4* src = reinterpret_cast<const float4*>(cw + kKiloSteps * 256);
+            reinterpret_cast<float4*>(sm_job)[lane] = src[lane];
+            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = src[64 + lane];
+        }
+        const float* bias_job = sm_job + kKOffBias + h * 16;
+        const float sb = cw[kKiloSteps * 256 + kKOffSigB], rb0 = cw[kKiloSteps * 256 + kKOffRgbB],
+                    rb1 = cw[kKiloSteps * 256 + kKOffRgbB + 1], rb2 = cw[kKiloSteps * 256 + kKOffRgbB + 2];
+        auto lds16 = [](const float* p) { return *reinterpret_cast<const f32x16*>(p); };
 
         // Gather pipeline: perm -> (point, dir index) -> direction is three dependent loads; indices run three
         // tiles ahead, points two, directions one.  Reads past the job's last tile are clamped to the segment's
@@ -268,20 +274,33 @@ __global__ __launch_bounds__(256, 1) void kilo_mlp_kernel(const float* __restric
             }
             f32x16 x[2];
             encode_pe_doubling<10>(px, py, pz, h, x);
-            x[0] = relu16(tiny_layer<2>(w, bias[0], x));                    // pts_linears 0 (network.py:132-138)
-            x[0] = relu16(tiny_layer<1>(w + 8, bias[1], x));                // pts_linears 1
+            // a run-time zero the compiler cannot see through: the LDS reads below are loop-invariant, and LICM
+            // would hoist all of them back into 128 registers held across the tile loop
+            int again = 0;
+            asm volatile("" : "+v"(again));
+            const float* bias_h = bias_job + again;
+            const float* sm = sm_job + again;
+            x[0] = relu16(tiny_layer<2>(w, lds16(bias_h), x));              // pts_linears 0 (network.py:132-138)
+            x[0] = relu16(tiny_layer<1>(w + 8, lds16(bias_h + 32), x));     // pts_linears 1
             float sigma = 0.f;                                              // sigma_linear (:142-144)
+            {
+                const f32x16 sw = lds16(sm + kKOffSigW + h * 16);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) sigma = fmaf(sw[t], x[0][t], sigma);
-            x[0] = tiny_layer<1>(w + 12, bias[2], x);                       // feature_linear (:147-149), no activation
+                for (int t = 0; t < 16; ++t) sigma = fmaf(sw[t], x[0][t], sigma);
+            }
+            x[0] = tiny_layer<1>(w + 12, lds16(bias_h + 64), x);            // feature_linear (:147-149), no activation
             encode_pe_doubling<4>(dx, dy, dz, h, x + 1);
-            const f32x16 hv = relu16(tiny_layer<2>(w + 16, bias[3], x));    // view_linears on cat([feature, dirs]) (:152-156)
+            const f32x16 hv = relu16(tiny_layer<2>(w + 16, lds16(bias_h + 96), x));  // view_linears on cat([feature, dirs]) (:152-156)
             float r = 0.f, g = 0.f, b = 0.f;                                // rgb_linear (:159-161)
+            {
+                const f32x16 r0 = lds16(sm + kKOffRgbW + h * 16), r1 = lds16(sm + kKOffRgbW + 32 + h * 16),
+                             r2 = lds16(sm + kKOffRgbW + 64 + h * 16);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                r = fmaf(rw[0][t], hv[t], r);
-                g = fmaf(rw[1][t], hv[t], g);
-                b = fmaf(rw[2][t], hv[t], b);
+                for (int t = 0; t < 16; ++t) {
+                    r = fmaf(r0[t], hv[t], r);
+                    g = fmaf(r1[t], hv[t], g);
+                    b = fmaf(r2[t], hv[t], b);
+                }
             }
             r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
             if (h == 0 && valid) raw[id] = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
@@ -568,10 +587,10 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
     kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, job_tiles, seg_start, cursor, job_prefix);
     kilo_scatter_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(cell, n_points, num_cells, cursor, perm);
     if (dir_index)
-        kilo_mlp_kernel<true><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
+        kilo_mlp_kernel<true><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
                                                                        dirs, dir_index, reinterpret_cast<float4*>(raw));
     else
-        kilo_mlp_kernel<false><<<dim3(unsigned(cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
+        kilo_mlp_kernel<false><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
                                                                         dirs, dir_index, reinterpret_cast<float4*>(raw));
     return nrf_launch_status();
 }
