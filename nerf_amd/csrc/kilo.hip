@@ -199,7 +199,10 @@ __global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict
 // operands stay in registers for the job (24 float4), biases and head rows are re-read per tile from a wave-private
 // LDS slice (as 128 more live registers they cost the second wave and, before that, 69 AGPR read-backs per tile),
 // gathers are prefetched three tiles ahead.  History: one wave per SIMD with everything in registers 3.99 ms,
-// small section in LDS 3.85 ms, two waves per SIMD 3.4 ms per 27.4 M-sample frame.
+// small section in LDS 3.85 ms, two waves per SIMD 3.4 ms per 27.4 M-sample frame.  That is the issue floor of this
+// instruction mix (837 tiles per SIMD x (96 x 64 + 540 x 4) cycles = 3.3 ms at 2.1 GHz): f32 MFMA and VALU share
+// the SIMD's issue cycles, so more waves do not help -- a workgroup-shared LDS copy of the whole cell record with
+// four waves per SIMD (112 registers) measured 3.5 ms.  Only fewer instructions per tile would.
 template <bool INDEXED>  // directions gathered through dir_index (one per ray) or given per point
 __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
                                                           const int* __restrict__ seg_start,
