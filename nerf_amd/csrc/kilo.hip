@@ -500,11 +500,22 @@ __global__ __launch_bounds__(256) void kilo_composite_kernel(const float4* __res
     if (ray >= n_rays) return;
     const int base = offsets[ray], n = counts[ray];
     float carry = 1.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f, sd = 0.f;
-    for (int c0 = 0; c0 < n && carry >= ert_eps; c0 += 64) {  // whole chunks past the threshold are skipped
+    // the next chunk's loads are issued before this chunk's scan (the termination test serialises the chunks of a
+    // ray otherwise: load -> scan -> test -> load ...); a chunk fetched behind the termination point is not used
+    auto fetch = [&](int c0, float4& rv, float& ts, float& te) {
         const int s = c0 + lane;
         const bool in = s < n;
-        const float4 rv = in ? raw[base + s] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float ts = in ? t_start[base + s] : 0.f, te = in ? t_end[base + s] : 0.f;
+        rv = in ? raw[base + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ts = in ? t_start[base + s] : 0.f, te = in ? t_end[base + s] : 0.f;
+    };
+    float4 rv_n;
+    float ts_n, te_n;
+    fetch(0, rv_n, ts_n, te_n);
+    for (int c0 = 0; c0 < n && carry >= ert_eps; c0 += 64) {  // whole chunks past the threshold are skipped
+        const bool in = c0 + lane < n;
+        const float4 rv = rv_n;
+        const float ts = ts_n, te = te_n;
+        fetch(c0 + 64, rv_n, ts_n, te_n);
         const PackedChunk k = packed_chunk(rv, te - ts, in, carry);
         const float w = k.T >= ert_eps ? k.T * k.alpha : 0.f;  // early ray termination: samples behind T < eps are dropped
         sr += w * k.cr, sg += w * k.cg, sb += w * k.cb;
