@@ -316,8 +316,10 @@ def kilo_train_bench(args, dev, rank, world, dist):
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (random pixels of orbit views, random targets, random-init cells, sphere occupancy)",
             "config": {"workload": "KiloNeRF distillation step (SURVEY 8f rank 3), %d-ray batch per rank, 4096 cells, "
-                                   "dense Adam over 25.4 M parameters, data-parallel RCCL all-reduce" % R,
-                       "rays_per_rank": R, "samples_per_step": n},
+                                   "dense Adam over 25.4 M parameters, data-parallel RCCL all-reduce of the sampled cells' "
+                                   "gradient records" % R,
+                       "rays_per_rank": R, "samples_per_step": n,
+                       "cells_exchanged": (int((ts.touched != 0).sum()) if ts.touched is not None else None)},
             "roofline": {"kernel": "clip_adam_kernel over the flat parameter buffer (dominant: the step is optimiser-bound)",
                          "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                          "note": "algorithmic bytes of the Adam pass = %.0f MB per step; see DESIGN.md section 7 for the "

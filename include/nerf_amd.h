@@ -258,6 +258,17 @@ int nrf_kilo_backward(const float* packed, const float* packed_t, int num_cells,
                       int64_t forward_workspace_bytes, float* const* grads_host, void* workspace,
                       int64_t workspace_bytes, nrf_stream_t stream);
 
+/* Compact form of a set of cells' slices of the 12 batched (cells, ...) tensors: record u = the 12 per-cell slices
+ * of cell cells[u] back to back (nrf_kilo_record_floats() = 6212 floats), `cells` a DEVICE list of distinct cell
+ * indices (< num_cells; not range-checked on the device).  For the data-parallel gradient exchange: only cells some
+ * rank has samples in carry a gradient, so the ranks all-reduce n_cells records instead of all 25.4 M values.
+ * The reference has no counterpart (DistributedDataParallel all-reduces every parameter, trainer.py:14-21). */
+int64_t nrf_kilo_record_floats(void);
+int nrf_kilo_cells_gather(const float* const* tensors_host, const int32_t* cells, int n_cells, int num_cells,
+                          float* records, nrf_stream_t stream);
+int nrf_kilo_cells_scatter(const float* records, const int32_t* cells, int n_cells, int num_cells,
+                           float* const* tensors_host, nrf_stream_t stream);
+
 /* *loss_accum += coeff * sum(p^2), grad_accum[i] += 2 coeff p[i] (either may be NULL): the colour regulariser
  * l2_reg * Network.get_color_reg_loss() (kilonerf/network.py:357-384, trainers/kilonerf.py:52-55), one call per
  * tensor (view_linears_{weights,biases}, rgb_linear_{weights,biases}). */

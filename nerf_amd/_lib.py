@@ -26,6 +26,7 @@ SYMBOLS = (
     "nrf_packed_bf16_bytes", "nrf_pack_weights_bf16", "nrf_mlp_forward_rays_bf16", "nrf_mlp_forward_points_bf16",
     "nrf_kilo_packed_bwd_floats", "nrf_kilo_pack_weights_transposed", "nrf_kilo_composite_backward",
     "nrf_kilo_backward_workspace_bytes", "nrf_kilo_backward", "nrf_l2_reg",
+    "nrf_kilo_record_floats", "nrf_kilo_cells_gather", "nrf_kilo_cells_scatter",
 )
 
 P = C.c_void_p
@@ -128,6 +129,12 @@ def lib() -> C.CDLL:
     L.nrf_kilo_backward_workspace_bytes.argtypes = [I64, INT]
     L.nrf_kilo_backward.argtypes = [P, P, INT, P, P, P, I64, P, P, I64, P, P, I64, P]
     L.nrf_l2_reg.argtypes = [P, I64, F, P, P, P]
+    L.nrf_kilo_record_floats.restype = I64
+    L.nrf_kilo_record_floats.argtypes = []
+    L.nrf_kilo_cells_gather.argtypes = [P, P, INT, INT, P, P]
+    L.nrf_kilo_cells_scatter.argtypes = [P, P, INT, INT, P, P]
+    L.nrf_kilo_cells_gather.restype = INT
+    L.nrf_kilo_cells_scatter.restype = INT
     for name in ("nrf_kilo_pack_weights_transposed", "nrf_kilo_composite_backward", "nrf_kilo_backward", "nrf_l2_reg"):
         getattr(L, name).restype = INT
     for name in ("nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward", "nrf_kilo_march_count",

@@ -446,7 +446,54 @@ __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ p
     if (threadIdx.x == 0 && loss) atomicAdd(loss, coeff * (s_part[0] + s_part[1] + s_part[2] + s_part[3]));
 }
 
+// ---- compact gradient exchange: the per-cell slices of the 12 tensors of a list of cells as records ----------
+// One workgroup per listed cell; every slice is a contiguous run on both sides (record = the 12 slices back to
+// back, kRecOff), so both directions are plain coalesced copies.
+template <bool GATHER>
+__global__ __launch_bounds__(256) void kilo_cells_copy_kernel(KiloSrc s, const int* __restrict__ cells,
+                                                              float* __restrict__ records) {
+    const int cell = cells[blockIdx.x];
+    float* rec = records + int64_t(blockIdx.x) * kRecFloats;
+#define COPY(K)                                                                                              \
+    for (int i = threadIdx.x; i < REC_OFF(K + 1) - REC_OFF(K); i += 256) {                                   \
+        float* g = const_cast<float*>(s.t[K]) + int64_t(cell) * (REC_OFF(K + 1) - REC_OFF(K)) + i;           \
+        if (GATHER) rec[REC_OFF(K) + i] = *g; else *g = rec[REC_OFF(K) + i];                                 \
+    }
+    COPY(0) COPY(1) COPY(2) COPY(3) COPY(4) COPY(5) COPY(6) COPY(7) COPY(8) COPY(9) COPY(10) COPY(11)
+#undef COPY
+}
+
 }  // namespace
+
+NRF_EXPORT int64_t nrf_kilo_record_floats(void) { return kRecFloats; }
+
+static int cells_copy(bool gather, const float* const* tensors, const int32_t* cells, int n_cells, int num_cells,
+                      float* records, nrf_stream_t stream) {
+    if (n_cells < 0 || num_cells <= 0 || n_cells > num_cells) return NRF_ERR_SHAPE;
+    if (n_cells == 0) return NRF_OK;
+    if (!tensors || !cells || !records) return NRF_ERR_NULL;
+    KiloSrc s;
+    for (int i = 0; i < 12; ++i) {
+        if (!tensors[i]) return NRF_ERR_NULL;
+        s.t[i] = tensors[i];
+    }
+    nrf_launch_begin();
+    if (gather)
+        kilo_cells_copy_kernel<true><<<dim3(unsigned(n_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, cells, records);
+    else
+        kilo_cells_copy_kernel<false><<<dim3(unsigned(n_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, cells, records);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_kilo_cells_gather(const float* const* tensors_host, const int32_t* cells, int n_cells, int num_cells,
+                                     float* records, nrf_stream_t stream) {
+    return cells_copy(true, tensors_host, cells, n_cells, num_cells, records, stream);
+}
+
+NRF_EXPORT int nrf_kilo_cells_scatter(const float* records, const int32_t* cells, int n_cells, int num_cells,
+                                      float* const* tensors_host, nrf_stream_t stream) {
+    return cells_copy(false, tensors_host, cells, n_cells, num_cells, const_cast<float*>(records), stream);
+}
 
 NRF_EXPORT int64_t nrf_kilo_packed_bwd_floats(int num_cells) {
     return num_cells <= 0 ? NRF_ERR_SHAPE : int64_t(num_cells) * kKiloCellTFloats;

@@ -148,6 +148,50 @@ def l2_reg(param: torch.Tensor, coeff: float, grad_accum: torch.Tensor | None, l
               "nrf_l2_reg")
 
 
+def _cell_tensors(tensors):
+    ts = list(tensors)
+    if len(ts) != 12:
+        raise NrfError("expected the 12 batched KiloNeRF tensors (KILO_TENSORS order)")
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == ts[0].shape[0]):
+            raise NrfError("kilo tensors: contiguous fp32 cuda tensors with the cell count as the first dimension")
+    return ts
+
+
+def kilo_cells_gather(tensors, cells: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """(len(cells), 6212) records: the 12 per-cell slices of every listed cell, back to back (nrf_kilo_cells_gather).
+    ``cells``: distinct int32 cell indices on the device."""
+    ts = _cell_tensors(tensors)
+    num_cells, dev = ts[0].shape[0], ts[0].device
+    if cells.dtype != torch.int32 or not cells.is_cuda or cells.ndim != 1:
+        raise NrfError("cells: expected a 1-D int32 cuda tensor")
+    n, rec = cells.shape[0], int(lib().nrf_kilo_record_floats())
+    if out is None:
+        out = torch.empty((n, rec), dtype=torch.float32, device=dev)
+    elif out.shape != (n, rec) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+        raise NrfError("out: expected a contiguous (len(cells), %d) fp32 tensor" % rec)
+    ptrs = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(dev):
+        check(lib().nrf_kilo_cells_gather(ptrs, _ptr(cells.contiguous()), n, num_cells, _ptr(out), _stream(out)),
+              "nrf_kilo_cells_gather")
+    return out
+
+
+def kilo_cells_scatter(records: torch.Tensor, cells: torch.Tensor, tensors) -> None:
+    """Inverse of kilo_cells_gather: writes the records back into the listed cells' slices; other cells are untouched."""
+    ts = _cell_tensors(tensors)
+    num_cells, dev = ts[0].shape[0], ts[0].device
+    n, rec = cells.shape[0], int(lib().nrf_kilo_record_floats())
+    if cells.dtype != torch.int32 or not cells.is_cuda or cells.ndim != 1:
+        raise NrfError("cells: expected a 1-D int32 cuda tensor")
+    if records.shape != (n, rec) or records.dtype != torch.float32 or not records.is_contiguous() or records.device != dev:
+        raise NrfError("records: expected a contiguous (len(cells), %d) fp32 tensor" % rec)
+    ptrs = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(dev):
+        check(lib().nrf_kilo_cells_scatter(_ptr(records), _ptr(cells.contiguous()), n, num_cells, ptrs, _stream(records)),
+              "nrf_kilo_cells_scatter")
+
+
 def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: float, step: float,
                reuse_masks: bool = True):
     """Occupancy-grid marching.  Returns (pts (N,3), ray_idx (N,), t_start (N,), t_end (N,),

@@ -11,7 +11,9 @@ src/train/trainers/trainer.py:68-75, optimiser src/train/optimizer.py:9-29, sche
 
 MI355X shape: the 12 batched parameter tensors live in ONE flat fp32 buffer (25.4 M floats; the module's
 parameters are re-pointed at views of it), the backward kernel writes ONE flat gradient buffer (every element,
-no memset), so data parallelism is a single RCCL all-reduce and the optimiser one fused kernel.  The autograd
+no memset), so data parallelism is a single RCCL all-reduce and the optimiser one fused kernel; with more than one
+rank the all-reduce carries only the cells some rank sampled (``parallel.allreduce_cell_gradients``: a quarter of
+the 102 MB for the sphere scene), the dense form stays available (``sparse_allreduce=False``).  The autograd
 route (``KiloRenderer.forward`` with ``is_training``) stays available for callers that own their optimiser.
 """
 from __future__ import annotations
@@ -19,20 +21,22 @@ from __future__ import annotations
 import torch
 
 from . import kilo_ops, ops
-from .parallel import allreduce_gradients
+from .parallel import allreduce_cell_gradients, allreduce_gradients
 from .weights import KILO_TENSORS
 
 _REG_TENSORS = ("view_linears_weights", "view_linears_biases", "rgb_linear_weights", "rgb_linear_biases")
 
 
 class KiloTrainStep:
-    def __init__(self, renderer, device, lr=5e-4, clip_value=40.0, l2_reg=1e-6, process_group=None):
+    def __init__(self, renderer, device, lr=5e-4, clip_value=40.0, l2_reg=1e-6, process_group=None,
+                 sparse_allreduce: bool = True):
         self.renderer = renderer
         self.net = renderer.net
         self.view = renderer.view
         self.device = torch.device(device)
         self.lr, self.clip, self.l2_reg = lr, clip_value, l2_reg
         self.group = process_group
+        self.sparse_allreduce = bool(sparse_allreduce)   # ranks exchange only the cells some rank sampled
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
@@ -57,6 +61,8 @@ class KiloTrainStep:
         self._packed_t = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.num_samples = 0
+        self.touched = None          # (cells,) int32 mask of the cells the last deferred-regulariser batch sampled
+        self._reg_pending = False
 
     def reset_optimizer(self, lr=None):
         """Fresh Adam state (the stage switch re-creates the optimiser, train_kilonerf.py:79-86)."""
@@ -66,8 +72,10 @@ class KiloTrainStep:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.t = 0
 
-    def forward_backward(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation"):
-        """Fills self.grad (all 12 tensors, flat) and self.loss; returns the render outputs."""
+    def forward_backward(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation", defer_reg=False):
+        """Fills self.grad (all 12 tensors, flat) and self.loss; returns the render outputs.  ``defer_reg``: leave
+        the colour regulariser out (``step`` adds it after a compact gradient exchange) and record in
+        ``self.touched`` which cells this batch sampled."""
         if stage not in ("distillation", "fine-tuning"):
             raise ValueError(f"stage {stage!r}: expected 'distillation' or 'fine-tuning' (train_kilonerf.py:74-78)")
         if stage == "distillation" and target_alpha is None:
@@ -93,13 +101,31 @@ class KiloTrainStep:
             g_acc = ops.mse_grad(acc, target_alpha.reshape(-1), self.loss)
         g_raw = kilo_ops.kilo_composite_backward(raw, ts, te, offsets, counts, r.ert, r.white_bkgd, g_rgb, None, g_acc)
         kilo_ops.kilo_backward(self._packed, self._packed_t, net.num_models, pts, d, ray_idx, g_raw, ws, grads=self.grads)
-        if distill and self.l2_reg > 0:   # the four regularised tensors are the tail of the flat buffer: one launch
+        self._reg_pending = bool(distill and self.l2_reg > 0)
+        if defer_reg:
+            self.touched = torch.zeros(net.num_models, dtype=torch.int32, device=o.device)
+            if pts.shape[0]:
+                self.touched.index_fill_(0, kilo_ops.kilo_route(pts, aabb, res).long(), 1)
+        elif self._reg_pending:   # the four regularised tensors are the tail of the flat buffer: one launch
             kilo_ops.l2_reg(self.flat[self._reg_begin:], self.l2_reg, self.grad[self._reg_begin:], self.loss)
+            self._reg_pending = False
         return {"rgb_map": rgb, "depth_map": depth, "alpha_map": acc}
 
     def step(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation"):
-        out = self.forward_backward(rays_o, rays_d, target_rgb, target_alpha, stage)
-        scale = allreduce_gradients(self.grad, self.group)   # DDP semantics: ONE flat sum all-reduce, mean in the kernel
+        sparse = self.world > 1 and self.sparse_allreduce
+        out = self.forward_backward(rays_o, rays_d, target_rgb, target_alpha, stage, defer_reg=sparse)
+        if sparse:
+            # DDP semantics (mean gradient) with a compact exchange: only cells some rank sampled travel.  The
+            # regulariser is the same on every rank and non-zero everywhere, so it is added afterwards, times
+            # world (the optimiser kernel divides the sum by world); its loss term is this rank's own.
+            scale = allreduce_cell_gradients(self.grads, self.touched, self.group)
+            if self._reg_pending:
+                tail = self.flat[self._reg_begin:]
+                kilo_ops.l2_reg(tail, self.l2_reg * self.world, self.grad[self._reg_begin:], None)
+                kilo_ops.l2_reg(tail, self.l2_reg, None, self.loss)
+                self._reg_pending = False
+        else:
+            scale = allreduce_gradients(self.grad, self.group)   # ONE flat sum all-reduce, mean in the kernel
         self.t += 1
         ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.t, lr=self.lr, clip_value=self.clip,
                       grad_scale=scale)

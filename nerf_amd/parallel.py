@@ -47,6 +47,43 @@ def allreduce_gradients(flat_grad: torch.Tensor, group=None) -> float:
     return 1.0 / world
 
 
+def _all_reduce(t: torch.Tensor, op, group=None) -> None:
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":              # rehearsal / CPU-only transport
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def allreduce_cell_gradients(grads, touched: torch.Tensor, group=None) -> float:
+    """Data-parallel exchange of KiloNeRF gradients in compact form ("sparse gradient
+    all-reduce").  ``grads``: the 12 batched (cells, ...) gradient tensors; ``touched`` (cells,) int32, non-zero
+    where THIS rank had samples -- every other cell's data gradient is exactly zero here.  The ranks agree on the
+    union of touched cells (one 16 KB MAX all-reduce), gather those cells' slices into (n, 6212) records
+    (``nrf_kilo_cells_gather``), sum-all-reduce the records and scatter them back: n / cells of the 102 MB a dense
+    exchange moves over xGMI (a quarter for the sphere scene of the bench).  Cells no rank touched keep their local
+    zeros, which is also their sum.  Returns 1 / world for the optimiser kernel, like ``allreduce_gradients``.
+    Terms that are identical on every rank and not zero outside the touched cells (the colour regulariser) must be
+    added AFTER this call, scaled by world (``KiloTrainStep.step`` does)."""
+    import torch.distributed as dist
+    from . import kilo_ops
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1.0
+    union = (touched != 0).to(torch.int32)
+    _all_reduce(union, dist.ReduceOp.MAX, group)
+    cells = union.nonzero().flatten().to(torch.int32)                # one host sync: the record count
+    if cells.numel():
+        rec = kilo_ops.kilo_cells_gather(grads, cells)
+        _all_reduce(rec, dist.ReduceOp.SUM, group)
+        kilo_ops.kilo_cells_scatter(rec, cells, grads)
+    return 1.0 / world
+
+
 def render_frame_sharded(render_rows, n_rays: int, rank: int, world: int, group=None, gather: bool = True):
     """Render rays ``shard_range(n_rays, rank, world)`` with ``render_rows(first_ray, count) -> dict`` of
     per-ray tensors ((count, C) or (count,)), and, if ``gather``, assemble all ranks' slices in ray
