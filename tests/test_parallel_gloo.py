@@ -109,3 +109,56 @@ def test_allreduce_gradients_without_process_group_is_identity():
 def test_frame_assembly_single_rank_passthrough():
     out, span = render_frame_sharded(_fake_render, 10, 0, 1)
     assert span == (0, 10) and torch.equal(out["fine_depth_map"], _fake_render(0, 10)["fine_depth_map"])
+
+
+def _cell_worker(rank, world, port, q):
+    """allreduce_cell_gradients' orchestration on CPU: the two HIP copies are replaced by their torch-indexing
+    equivalents (tests/test_gpu_kilo_ddp.py checks the kernels against exactly these), everything else -- union of
+    the touched masks, record all-reduce, scatter, the returned scale -- is the product code."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_amd import kilo_ops, parallel
+        kilo_ops.kilo_cells_gather = lambda ts, cells, out=None: torch.cat(
+            [t.reshape(t.shape[0], -1)[cells.long()] for t in ts], 1).contiguous()
+
+        def scatter(rec, cells, ts):
+            c0 = 0
+            for t in ts:
+                w = t[0].numel()
+                t.reshape(t.shape[0], -1)[cells.long()] = rec[:, c0:c0 + w]
+                c0 += w
+        kilo_ops.kilo_cells_scatter = scatter
+        ncell = 32
+        g = torch.Generator().manual_seed(100 + rank)
+        touched = torch.zeros(ncell, dtype=torch.int32)
+        touched[torch.randperm(ncell, generator=g)[:10]] = 1
+        shapes = [(ncell, 3, 2), (ncell, 5)]
+        grads = [torch.randn(s, generator=g) * touched.view(-1, *([1] * (len(s) - 1))) for s in shapes]
+        dense = [t.clone() for t in grads]
+        for t in dense:
+            dist.all_reduce(t)
+        scale = parallel.allreduce_cell_gradients(grads, touched)
+        ok = scale == 0.5 and all(torch.equal(a, b) for a, b in zip(grads, dense))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_cell_gradient_exchange_matches_dense_sum():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 3 + 11) % 2000
+    procs = [ctx.Process(target=_cell_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_cell_gradient_exchange_single_process_is_identity():
+    from nerf_amd.parallel import allreduce_cell_gradients
+    g = [torch.ones(4, 2)]
+    assert allreduce_cell_gradients(g, torch.ones(4, dtype=torch.int32)) == 1.0 and torch.all(g[0] == 1)
