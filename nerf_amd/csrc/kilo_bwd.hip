@@ -73,9 +73,25 @@ __global__ __launch_bounds__(256) void kilo_grad_reduce_kernel(const float* __re
                                                                const int* __restrict__ job_prefix, KiloGrad g) {
     const int cell = blockIdx.x;
     const int j0 = job_prefix[cell], j1 = job_prefix[cell + 1];
-    for (int e = threadIdx.x; e < kRecFloats; e += 256) {
-        float acc = 0.f;
-        for (int j = j0; j < j1; ++j) acc += partial[int64_t(j) * kRecStride + e];
+    // jobs outside, elements inside: the 25 loads a thread makes per job are independent and in flight together
+    // (elements outside made every thread walk its jobs as 25 separate dependent-latency chains)
+    constexpr int kPer = (kRecFloats + 255) / 256;
+    float sum[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) sum[k] = 0.f;
+    for (int j = j0; j < j1; ++j) {
+        const float* rec = partial + int64_t(j) * kRecStride;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            sum[k] += e < kRecFloats ? rec[e] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        if (e >= kRecFloats) break;
+        const float acc = sum[k];
         int t = 0, off = 0, size = REC_OFF(1);
 #define REC_CASE(k) if (e >= REC_OFF(k)) t = k, off = REC_OFF(k), size = REC_OFF(k + 1) - REC_OFF(k);
         REC_CASE(1) REC_CASE(2) REC_CASE(3) REC_CASE(4) REC_CASE(5) REC_CASE(6) REC_CASE(7) REC_CASE(8) REC_CASE(9)
