@@ -446,13 +446,36 @@ __global__ __launch_bounds__(256) void kilo_composite_bwd_kernel(const float4* _
 }
 
 // loss += coeff * sum(p^2); grad += 2 coeff p   (kilonerf/network.py:378-382 under l2_reg, trainers/kilonerf.py:52-55)
+template <bool VEC4>  // VEC4: both pointers 16-byte aligned; the n % 4 tail is handled by the last scalar lanes
 __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ p, int64_t n, float coeff,
                                                      float* __restrict__ grad, float* __restrict__ loss) {
     float acc = 0.f;
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const float v = p[i];
-        acc = fmaf(v, v, acc);
-        if (grad) grad[i] = fmaf(2.f * coeff, v, grad[i]);
+    const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride = int64_t(gridDim.x) * blockDim.x;
+    const float c2 = 2.f * coeff;
+    if (VEC4) {
+        const int64_t n4 = n >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        float4* g4 = reinterpret_cast<float4*>(grad);
+        for (int64_t i = tid; i < n4; i += stride) {
+            const float4 v = p4[i];
+            acc = fmaf(v.x, v.x, acc), acc = fmaf(v.y, v.y, acc), acc = fmaf(v.z, v.z, acc), acc = fmaf(v.w, v.w, acc);
+            if (grad) {
+                float4 g = g4[i];
+                g.x = fmaf(c2, v.x, g.x), g.y = fmaf(c2, v.y, g.y), g.z = fmaf(c2, v.z, g.z), g.w = fmaf(c2, v.w, g.w);
+                g4[i] = g;
+            }
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {
+            const float v = p[i];
+            acc = fmaf(v, v, acc);
+            if (grad) grad[i] = fmaf(c2, v, grad[i]);
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += stride) {
+            const float v = p[i];
+            acc = fmaf(v, v, acc);
+            if (grad) grad[i] = fmaf(c2, v, grad[i]);
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
@@ -624,7 +647,10 @@ NRF_EXPORT int nrf_l2_reg(const float* params, int64_t n, float coeff, float* gr
     if (!params) return NRF_ERR_NULL;
     const int64_t blocks = (n + 255) / 256;
     nrf_launch_begin();
-    l2_reg_kernel<<<dim3(unsigned(blocks < 1024 ? blocks : 1024)), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        params, n, coeff, grad_accum, loss_accum);
+    const unsigned grid = unsigned(blocks < 2048 ? blocks : 2048);
+    if (nrf_aligned16(params) && (!grad_accum || nrf_aligned16(grad_accum)))
+        l2_reg_kernel<true><<<dim3(grid), 256, 0, static_cast<hipStream_t>(stream)>>>(params, n, coeff, grad_accum, loss_accum);
+    else
+        l2_reg_kernel<false><<<dim3(grid), 256, 0, static_cast<hipStream_t>(stream)>>>(params, n, coeff, grad_accum, loss_accum);
     return nrf_launch_status();
 }

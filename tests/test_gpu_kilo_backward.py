@@ -311,3 +311,23 @@ def test_renderer_autograd_with_no_samples(dev):
     (out["rgb_map"].sum() + out["alpha_map"].sum()).backward()
     for p in net.model.tensors():
         assert p.grad is not None and torch.all(p.grad == 0)
+
+
+@pytest.mark.parametrize("n,offset", [(1, 0), (5, 0), (1027, 0), (4096, 1), (100003, 3), (1 << 20, 0)])
+def test_l2_reg_sizes_and_alignments(dev, n, offset):
+    """float4 body + scalar tail, and the scalar kernel for views that are not 16-byte aligned."""
+    from nerf_amd import kilo_ops
+    g = torch.Generator(device=dev).manual_seed(n)
+    base_p = torch.randn(n + 8, device=dev, generator=g)
+    base_g = torch.randn(n + 8, device=dev, generator=g)
+    p, grad = base_p[offset:offset + n], base_g[offset:offset + n]
+    want_g = grad + 2 * 1e-3 * p
+    want_l = 1e-3 * float((p.double() ** 2).sum())
+    loss = torch.zeros(1, device=dev)
+    kilo_ops.l2_reg(p, 1e-3, grad, loss)
+    assert torch.allclose(grad, want_g, rtol=1e-6, atol=1e-7)
+    assert abs(float(loss) - want_l) <= 1e-5 * max(1.0, want_l)
+    assert torch.equal(base_g[offset + n:], base_g[offset + n:]) and torch.isfinite(base_g).all()
+    loss.zero_()
+    kilo_ops.l2_reg(p, 1e-3, None, loss)                       # loss only
+    assert abs(float(loss) - want_l) <= 1e-5 * max(1.0, want_l)
