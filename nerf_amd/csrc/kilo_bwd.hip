@@ -456,7 +456,29 @@ __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ p
         const int64_t n4 = n >> 2;
         const float4* p4 = reinterpret_cast<const float4*>(p);
         float4* g4 = reinterpret_cast<float4*>(grad);
-        for (int64_t i = tid; i < n4; i += stride) {
+        // four float4 per thread and iteration in flight; few blocks, because every block ends in one atomic on
+        // the loss word and those serialise (1024 blocks: 40 us for this kernel, whatever its loop did)
+        int64_t i = tid;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            float4 v[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p4[i + u * stride];
+            if (grad) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = g4[i + u * stride];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = fmaf(v[u].x, v[u].x, acc), acc = fmaf(v[u].y, v[u].y, acc);
+                acc = fmaf(v[u].z, v[u].z, acc), acc = fmaf(v[u].w, v[u].w, acc);
+                if (grad) {
+                    g[u].x = fmaf(c2, v[u].x, g[u].x), g[u].y = fmaf(c2, v[u].y, g[u].y);
+                    g[u].z = fmaf(c2, v[u].z, g[u].z), g[u].w = fmaf(c2, v[u].w, g[u].w);
+                    g4[i + u * stride] = g[u];
+                }
+            }
+        }
+        for (; i < n4; i += stride) {
             const float4 v = p4[i];
             acc = fmaf(v.x, v.x, acc), acc = fmaf(v.y, v.y, acc), acc = fmaf(v.z, v.z, acc), acc = fmaf(v.w, v.w, acc);
             if (grad) {
@@ -647,7 +669,7 @@ NRF_EXPORT int nrf_l2_reg(const float* params, int64_t n, float coeff, float* gr
     if (!params) return NRF_ERR_NULL;
     const int64_t blocks = (n + 255) / 256;
     nrf_launch_begin();
-    const unsigned grid = unsigned(blocks < 2048 ? blocks : 2048);
+    const unsigned grid = unsigned(blocks < 512 ? blocks : 512);
     if (nrf_aligned16(params) && (!grad_accum || nrf_aligned16(grad_accum)))
         l2_reg_kernel<true><<<dim3(grid), 256, 0, static_cast<hipStream_t>(stream)>>>(params, n, coeff, grad_accum, loss_accum);
     else
