@@ -204,9 +204,13 @@ def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: fl
     R = rays_o.shape[0]
     dev = rays_o.device
     _a, _r, pa, pr = _grid_args(aabb, occ.shape)
-    counts = torch.zeros(R, dtype=torch.int32, device=dev)
-    offsets = torch.zeros(R, dtype=torch.int32, device=dev)
-    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    if R == 0:
+        e = torch.empty(0, dtype=torch.float32, device=dev)
+        z = torch.empty(0, dtype=torch.int32, device=dev)
+        return e.reshape(0, 3), z, e, e.clone(), z.clone(), z.clone()
+    counts = torch.empty(R, dtype=torch.int32, device=dev)      # the count pass writes every ray's entry,
+    offsets = torch.empty(R, dtype=torch.int32, device=dev)     # the scan every offset and the total
+    total = torch.empty(1, dtype=torch.int64, device=dev)
     need = int(lib().nrf_kilo_march_workspace_bytes(R, float(t_near), float(t_far), float(step)))
     if need < 0:
         check(need, "nrf_kilo_march_workspace_bytes")
