@@ -170,6 +170,38 @@ def train_bench(args, net, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def kilo_cpu_baseline(seconds: float, sd, frame_samples: float):
+    """oracle/kilo_oracle.py (the reference's batched-bmm network over this repository's marching / compositing
+    rule) on 128-ray slices of the bench view's central rows until ~`seconds` of CPU time."""
+    from oracle import kilo_oracle as K
+    from oracle import nerf_oracle as O
+    from nerf_amd.camera import pose_spherical, LEGO_CAMERA_ANGLE_X
+    c = (np.arange(256, dtype=np.float32) + 0.5) / 256 * 2 - 1
+    occ = (np.sqrt(c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2) < 0.75).astype(np.uint8)
+    o, d = O.raygen(pose_spherical(0.0), H, W, LEGO_CAMERA_ANGLE_X)
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    chunk, done, samples, t0 = 128, 0, 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            r0 = (250 + (done // chunk) % 300) * W + 336       # 128 central pixels of rows 250 .. 549
+            out = K.render(sdt, o[r0:r0 + chunk], d[r0:r0 + chunk], occ, [-1.0] * 3, [1.0] * 3, [16, 16, 16], 2.0, 6.0,
+                           0.005, 0.01, True)
+            samples += int(out["n_samples"])
+            done += chunk
+            el = time.perf_counter() - t0
+            if el >= seconds or done >= 1024 * chunk:
+                break
+    return {"value": done / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} rays through the sphere (central 128 pixels of rows 250+ of the same view), "
+                      f"oracle/kilo_oracle.py on torch-CPU fp32, {el:.1f} s; host has {os.cpu_count()} logical CPUs; "
+                      f"{samples / done:.0f} samples per ray here (these rays all cross the occupied sphere), "
+                      "43 per ray over the whole frame",
+            "samples_per_s": samples / el,
+            "ms_per_frame_extrapolated": 1e3 * frame_samples / max(samples / el, 1e-9),
+            "extrapolation": "by evaluated samples (the frame's samples / the sample rate measured here)"}
+
+
 def kilo_bench(args, dev, rank, world, dist):
     """BASELINE configs[3]: KiloNeRF, 4096 cells (W=32, D=2), occupancy = sphere |x| < 0.75 at 256^3, step 0.005,
     ERT 0.01, near 2 / far 6, 800x800 view per rank per step (weak scaling, no data-path collective)."""
@@ -235,7 +267,7 @@ def kilo_bench(args, dev, rank, world, dist):
         ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
         n = float(np.mean(samples))
         flop = 12160.0 * n                                    # 6080 MACs per evaluated sample
-        print(json.dumps({
+        line = {
             "metric": "rays/sec (KiloNeRF 800x800 frame, occupancy-grid marching + early termination)",
             "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -248,7 +280,10 @@ def kilo_bench(args, dev, rank, world, dist):
                          "achieved": flop / (ms["mlp"] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "samples_per_s": n / (ms["mlp"] * 1e-3)},
-            "stage_ms": ms}), flush=True)
+            "stage_ms": ms}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = kilo_cpu_baseline(args.cpu_seconds, sd, n)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
