@@ -107,6 +107,38 @@ def cpu_baseline(seconds: float):
             "ms_per_frame_extrapolated": 1e3 * H * W * el / done}
 
 
+def train_cpu_baseline(seconds: float, rays_per_step: int = 256):
+    """The training step of trainer.py:68-75 on the CPU: oracle forward (perturbed samples), torch autograd,
+    clip_grad_value_(40), torch.optim.Adam(5e-4), on batches of `rays_per_step` random pixels until ~`seconds`."""
+    from oracle import nerf_oracle as O
+    from nerf_amd.weights import make_state_dict
+    from nerf_amd.camera import pose_spherical, LEGO_CAMERA_ANGLE_X
+    sd = {k: v.clone().requires_grad_(True) for k, v in make_state_dict(0, 30.0, 2.0).items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=5e-4)
+    o, d = O.raygen(pose_spherical(0.0), H, W, LEGO_CAMERA_ANGLE_X)
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    rng = np.random.Generator(np.random.PCG64(1))
+    done, steps, t0 = 0, 0, time.perf_counter()
+    while True:
+        pix = rng.integers(0, H * W, rays_per_step)
+        u, u2, uf = (rng.random((rays_per_step, N_IMPORTANCE), dtype=np.float32) for _ in range(3))
+        uc = rng.random((rays_per_step, N_COARSE), dtype=np.float32)
+        gt = torch.from_numpy(rng.random((rays_per_step, 3), dtype=np.float32))
+        out = O.render(sd, o[pix], d[pix], u=u, u2=u2, u_coarse=uc, u_fine=uf)
+        opt.zero_grad(set_to_none=True)
+        O.loss(out, gt).backward()
+        torch.nn.utils.clip_grad_value_(list(sd.values()), 40.0)
+        opt.step()
+        done += rays_per_step
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 256:
+            break
+    return {"value": done / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of {rays_per_step} random pixels (fwd + autograd + clip + Adam), oracle/nerf_oracle.py on "
+                      f"torch-CPU fp32, {el:.1f} s; host has {os.cpu_count()} logical CPUs"}
+
+
 def train_bench(args, net, dev, rank, world, dist):
     """BASELINE configs[2]: per rank 4096 random pixels of one view, perturb=1, fwd + 2xMSE + bwd +
     gradient all-reduce (mean) + clip 40 + Adam(5e-4).  Weak scaling: every rank has its own batch."""
@@ -153,7 +185,7 @@ def train_bench(args, net, dev, rank, world, dist):
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         flop = 3.0 * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT   # fwd + dgrad + wgrad, SURVEY 8d
-        print(json.dumps({
+        line = {
             "metric": "training rays/sec (fwd+bwd+Adam step, 64 coarse + 128 fine samples/ray)",
             "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -164,7 +196,10 @@ def train_bench(args, net, dev, rank, world, dist):
                          "achieved": flop / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "note": "algorithmic FLOPs of the step / wall time of the step, not one kernel"},
-            "final_loss": loss}), flush=True)
+            "final_loss": loss}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = train_cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
