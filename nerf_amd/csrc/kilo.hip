@@ -75,7 +75,8 @@ __device__ __forceinline__ int route_cell(const Grid& g, float x, float y, float
     int idx[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float n = __fdiv_rn(__fsub_rn(p[a], g.mn[a]), __fsub_rn(g.mx[a], g.mn[a]));
+        const float n = __fdiv_rn(__fsub_rn(p[a], g.mn[a]), __fsub_rn(g.mx[a], g.mn[a]));  // (the kernel is bound by
+        // its loads: the exact-reciprocal form the march uses for power-of-two boxes measured no faster here)
         float s = __fmul_rn(n, float(g.res[a]));
         s = s < 0.f ? 0.f : s;                  // torch.clamp(min=0): NaN stays NaN -> (int) 0 below
         const float hi = float(g.res[a]) - 1.0f;
@@ -363,7 +364,6 @@ __global__ void scan_add_kernel(int* __restrict__ out, int64_t n, const int* __r
 struct March {
     Grid g;          // scene box + occupancy resolution
     float t_near, t_far, step;
-    float inv[3];    // 1 / (max - min) when that is exact (see march_exact_inverse), else unused
 };
 
 // Interval k of a ray is [t0 + k*step, min(t0 + (k+1)*step, t1)) with [t0, t1] = ray-box overlap
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void kilo_march_kernel(March m, const float* _
                 int v[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const float s = (PINV ? (p[a] - m.g.mn[a]) * m.inv[a] : (p[a] - m.g.mn[a]) / (m.g.mx[a] - m.g.mn[a])) *
+                    const float s = (PINV ? (p[a] - m.g.mn[a]) * m.g.inv[a] : (p[a] - m.g.mn[a]) / (m.g.mx[a] - m.g.mn[a])) *
                                     float(m.g.res[a]);
                     v[a] = int(fminf(fmaxf(s, 0.f), float(m.g.res[a]) - 1.0f));
                 }
@@ -625,18 +625,6 @@ static int march_max_chunks(float t_near, float t_far, float step) {
     if (!(steps < double(1 << 22))) return -1;
     return int(steps) / 64 + 2;
 }
-// x / e == x * (1 / e) bit for bit when e is a power of two (and 1 / e is a normal float)
-static bool march_exact_inverse(March& m) {
-    bool all = true;
-    for (int a = 0; a < 3; ++a) {
-        const float e = m.g.mx[a] - m.g.mn[a];
-        int ex = 0;
-        const bool pow2 = e > 0.f && std::frexp(e, &ex) == 0.5f && ex > -100 && ex < 100;
-        m.inv[a] = pow2 ? 1.0f / e : 0.f;
-        all = all && pow2;
-    }
-    return all;
-}
 static int64_t march_scan_bytes(int64_t n_rays) { return a256(((n_rays + kScanBlock - 1) / kScanBlock + 1) * 4); }
 
 NRF_EXPORT int64_t nrf_kilo_march_workspace_bytes(int64_t n_rays, float t_near, float t_far, float step) {
@@ -659,8 +647,8 @@ NRF_EXPORT int nrf_kilo_march_count(const float* rays_o, const float* rays_d, in
     if (mc < 0) return NRF_ERR_SHAPE;
     if (workspace_bytes < nrf_kilo_march_workspace_bytes(n_rays, t_near, t_far, step)) return NRF_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    March m{make_grid(aabb_host, occ_res_host), t_near, t_far, step, {0.f, 0.f, 0.f}};
-    const bool pinv = march_exact_inverse(m);
+    March m{make_grid(aabb_host, occ_res_host), t_near, t_far, step};
+    const bool pinv = m.g.pinv != 0;
     const int64_t blocks = (n_rays + 3) / 4;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
     auto* masks = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + march_scan_bytes(n_rays));
@@ -691,8 +679,8 @@ NRF_EXPORT int nrf_kilo_march_write(const float* rays_o, const float* rays_d, in
     if (n_rays == 0) return NRF_OK;
     if (int st = check_march(rays_o, rays_d, occ, aabb_host, occ_res_host, t_near, t_far, step)) return st;
     if (!offsets || !pts || !ray_idx || !t_start || !t_end) return NRF_ERR_NULL;
-    March m{make_grid(aabb_host, occ_res_host), t_near, t_far, step, {0.f, 0.f, 0.f}};
-    const bool pinv = march_exact_inverse(m);
+    March m{make_grid(aabb_host, occ_res_host), t_near, t_far, step};
+    const bool pinv = m.g.pinv != 0;
     const int64_t blocks = (n_rays + 3) / 4;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);

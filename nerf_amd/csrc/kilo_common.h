@@ -1,5 +1,7 @@
 // Shared pieces of the KiloNeRF kernels (kilo.hip: forward / marching / compositing, kilo_bwd.hip: backward).
 #pragma once
+#include <cmath>
+
 #include "mlp_chain.h"
 
 namespace {
@@ -42,6 +44,8 @@ __device__ __forceinline__ void stage_cell_record(const KiloSrc& s, int cell, fl
 struct Grid {
     float mn[3], mx[3];
     int res[3];
+    float inv[3];  // 1 / (max - min) where that edge is a power of two (x / e == x * (1 / e) bit for bit), else 0
+    int pinv;      // all three edges are: the voxel / cell formulas multiply instead of dividing
 };
 
 // One 32x32 output block of a tiny layer: Y = init + sum_k W . x over NKB k-blocks of 32.
@@ -63,7 +67,15 @@ __device__ __forceinline__ f32x16 tiny_layer(const float4* w, f32x16 init, const
 
 __attribute__((unused)) Grid make_grid(const float* aabb, const int* res) {
     Grid g;
-    for (int a = 0; a < 3; ++a) g.mn[a] = aabb[a], g.mx[a] = aabb[3 + a], g.res[a] = res[a];
+    g.pinv = 1;
+    for (int a = 0; a < 3; ++a) {
+        g.mn[a] = aabb[a], g.mx[a] = aabb[3 + a], g.res[a] = res[a];
+        const float e = g.mx[a] - g.mn[a];
+        int ex = 0;
+        const bool pow2 = e > 0.f && std::frexp(e, &ex) == 0.5f && ex > -100 && ex < 100;
+        g.inv[a] = pow2 ? 1.0f / e : 0.f;
+        g.pinv = g.pinv && pow2;
+    }
     return g;
 }
 

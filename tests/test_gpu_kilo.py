@@ -325,3 +325,21 @@ def test_march_random_configurations_both_write_paths(dev):
         idx = np.concatenate([np.arange(off[r], off[r] + cnt[r]) for r in sub]) if cnt[sub].sum() else np.zeros(0, int)
         assert np.array_equal(a[0].cpu().numpy()[idx], ref[0]), trial
         assert np.array_equal(a[2].cpu().numpy()[idx], ref[2]) and np.array_equal(a[3].cpu().numpy()[idx], ref[3]), trial
+
+
+@pytest.mark.parametrize("box", [[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], [-2.0, -0.5, -1.0, 2.0, 0.5, 1.0],
+                                 [-1.3, -0.9, -1.0, 1.1, 1.2, 0.7], [-1.0, -1.0, -1.0, 1.0, 1.0, 0.5]])
+def test_route_other_boxes_vs_oracle(dev, box):
+    """Boxes other than the fixture's [-1, 1]^3, with equal, unequal, power-of-two and other edges: the oracle's
+    (= the reference formula's) cell for points on, inside and outside the box."""
+    from nerf_amd import kilo_ops
+    from oracle import kilo_oracle as K
+    rng = np.random.default_rng(5)
+    lo, hi = np.array(box[:3], np.float32), np.array(box[3:], np.float32)
+    pts = (lo + (hi - lo) * rng.uniform(-0.1, 1.1, size=(20000, 3))).astype(np.float32)
+    grid = (np.arange(17, dtype=np.float32) / 16)[:, None] * (hi - lo) + lo          # points on the cell faces
+    pts = np.concatenate([pts, np.stack(np.meshgrid(grid[:, 0], grid[:, 1], grid[:, 2], indexing="ij"), -1).reshape(-1, 3)])
+    res = [16, 16, 16]
+    got = kilo_ops.kilo_route(_t(pts, dev), box, res).cpu().numpy()
+    _idx3, want = K.route(pts, box[:3], box[3:], res)
+    assert np.array_equal(got, np.asarray(want).astype(np.int32))
