@@ -91,6 +91,9 @@ __device__ __forceinline__ int route_cell(const Grid& g, float x, float y, float
 // touches only a dozen cells: a block owns one chunk, histograms it in LDS and sends one global atomic per touched
 // cell (a grid-stride block would see every occupied cell and send ~900).
 constexpr int kSortChunk = 4096;
+// the routing kernel keeps nothing per point in registers, so its chunk can be larger: zeroing and flushing the
+// 4096-entry LDS histogram costs a block as much as routing 4096 points
+constexpr int kRouteChunk = 16384;
 __global__ __launch_bounds__(256) void kilo_route_kernel(Grid g, const float* __restrict__ pts, int64_t n,
                                                          int* __restrict__ cell, int* __restrict__ hist) {
     extern __shared__ int s_hist[];
@@ -98,12 +101,26 @@ __global__ __launch_bounds__(256) void kilo_route_kernel(Grid g, const float* __
     if (hist)
         for (int i = threadIdx.x; i < ncell; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
-    const int64_t begin = int64_t(blockIdx.x) * kSortChunk;
-    const int64_t end = begin + kSortChunk < n ? begin + kSortChunk : n;
-    for (int64_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
-        const int c = route_cell(g, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
-        cell[i] = c;
-        if (hist) atomicAdd(&s_hist[c], 1);
+    const int64_t begin = int64_t(blockIdx.x) * kRouteChunk;
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < kRouteChunk / 256; ++k) {  // every lane runs every round: the run detection needs full waves
+        const int64_t i = begin + k * 256 + threadIdx.x;
+        const bool in = i < n;
+        int c = -1;
+        if (in) {
+            struct P3 { float x, y, z; };   // one 12-byte load per lane instead of three strided 4-byte ones
+            const P3 p = reinterpret_cast<const P3*>(pts)[i];
+            c = route_cell(g, p.x, p.y, p.z);
+            cell[i] = c;
+        }
+        if (hist) {  // one LDS atomic per run of equal cells (per point they collide 64-wide: a ray stays in a cell)
+            const int prev = __shfl_up(c, 1);
+            const bool head = lane == 0 || c != prev;
+            const unsigned long long heads = __ballot(head);
+            const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+            const int next_head = after ? __ffsll((long long)after) - 1 : 64;
+            if (head && c >= 0) atomicAdd(&s_hist[c], next_head - lane);
+        }
     }
     __syncthreads();
     if (hist)
@@ -559,7 +576,7 @@ NRF_EXPORT int nrf_kilo_route(const float* pts, int64_t n, const float* aabb_hos
     if (!pts || !aabb_host || !res_host || !cell) return NRF_ERR_NULL;
     const Grid g = make_grid(aabb_host, res_host);
     if (g.res[0] <= 0 || g.res[1] <= 0 || g.res[2] <= 0) return NRF_ERR_SHAPE;
-    const int64_t blocks = (n + kSortChunk - 1) / kSortChunk;   // one contiguous chunk per block
+    const int64_t blocks = (n + kRouteChunk - 1) / kRouteChunk;   // one contiguous chunk per block
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
     nrf_launch_begin();
     kilo_route_kernel<<<dim3(unsigned(blocks)), 256, 0, static_cast<hipStream_t>(stream)>>>(g, pts, n, cell, nullptr);
@@ -594,7 +611,8 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
     nrf_launch_begin();
     (void)hipMemsetAsync(hist, 0, size_t(num_cells + 1) * 4, stream);
     const unsigned rb = unsigned((n_points + kSortChunk - 1) / kSortChunk);   // n_points <= 2^28: at most 65536 blocks
-    kilo_route_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(g, pts, n_points, cell, hist);
+    kilo_route_kernel<<<dim3(unsigned((n_points + kRouteChunk - 1) / kRouteChunk)), 256, size_t(num_cells) * 4, stream>>>(
+        g, pts, n_points, cell, hist);
     // tiles of one cell per weight load: up to kJobTiles, fewer for small batches so that every wavefront gets jobs
     int64_t jt = (n_points + 32 * 4 * int64_t(cus) * 4 - 1) / (32 * 4 * int64_t(cus) * 4);
     const int job_tiles = int(jt < 4 ? 4 : jt > kJobTiles ? kJobTiles : jt);
