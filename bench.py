@@ -324,6 +324,45 @@ def kilo_bench(args, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def kilo_train_cpu_baseline(seconds: float, sd, rays_per_step: int = 256):
+    """The KiloNeRF distillation step on the CPU: oracle march + the reference's batched network + the packed
+    compositing rule in torch, autograd, clip 40, torch.optim.Adam over all 25.4 M parameters (dense, as in the
+    reference), batches of `rays_per_step` random pixels until ~`seconds`."""
+    from oracle import kilo_oracle as K
+    from oracle import nerf_oracle as O
+    from nerf_amd.camera import pose_spherical, LEGO_CAMERA_ANGLE_X
+    c = (np.arange(256, dtype=np.float32) + 0.5) / 256 * 2 - 1
+    occ = (np.sqrt(c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2) < 0.75).astype(np.uint8)
+    o, d = O.raygen(pose_spherical(0.0), H, W, LEGO_CAMERA_ANGLE_X)
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    sdt = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items() if v.dtype == np.float32 and v.ndim > 1}
+    full = {k: (sdt[k] if k in sdt else torch.from_numpy(v)) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(sdt.values()), lr=5e-4)
+    rng = np.random.Generator(np.random.PCG64(2))
+    done, steps, samples, t0 = 0, 0, 0, time.perf_counter()
+    while True:
+        pix = rng.integers(0, H * W, rays_per_step)
+        t_rgb = torch.from_numpy(rng.random((rays_per_step, 3), dtype=np.float32))
+        t_alpha = torch.from_numpy(rng.random((rays_per_step, 1), dtype=np.float32))
+        pts, ri, ts, te, off, cnt = K.march(o[pix], d[pix], occ, [-1.0] * 3, [1.0] * 3, 2.0, 6.0, 0.005)
+        raw = K.network_forward(full, torch.from_numpy(pts), torch.from_numpy(d[pix][ri]), [-1.0] * 3, [1.0] * 3, [16, 16, 16])
+        rgb, _depth, acc = K.composite_packed_torch(raw, ts, te, off, cnt, 0.01, True)
+        opt.zero_grad(set_to_none=True)
+        K.train_loss(rgb, acc, t_rgb, t_alpha, "distillation", 1e-6, full).backward()
+        torch.nn.utils.clip_grad_value_(list(sdt.values()), 40.0)
+        opt.step()
+        done += rays_per_step
+        steps += 1
+        samples += len(pts)
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 256:
+            break
+    return {"value": done / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of {rays_per_step} random pixels ({samples / max(steps, 1):.0f} samples per step; march + "
+                      f"batched network + packed compositing + autograd + clip + dense Adam), oracle/kilo_oracle.py on torch-CPU, "
+                      f"{el:.1f} s; host has {os.cpu_count()} logical CPUs"}
+
+
 def kilo_train_bench(args, dev, rank, world, dist):
     """KiloNeRF distillation step (configs/kilonerf/lego.yaml: batch_size 4 x N_rays 1024 rays per rank):
     march + tiny MLPs + packed compositing, mse(rgb) + mse(alpha) + l2_reg colour regulariser, backward, gradient
@@ -380,7 +419,7 @@ def kilo_train_bench(args, dev, rank, world, dist):
         ms = 1e3 * elapsed / args.steps
         n = float(np.mean(samples[args.warmup:]))
         adam_bytes = 28.0 * ts.flat.numel()                  # 16 B read + 12 B write per parameter
-        print(json.dumps({
+        line = {
             "metric": "training rays/sec (KiloNeRF distillation step: fwd+bwd+Adam)",
             "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -394,7 +433,10 @@ def kilo_train_bench(args, dev, rank, world, dist):
                          "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                          "note": "algorithmic bytes of the Adam pass = %.0f MB per step; see DESIGN.md section 7 for the "
                                  "per-kernel times (rocprofv3)" % (adam_bytes / 1e6)},
-            "final_loss": loss}), flush=True)
+            "final_loss": loss}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = kilo_train_cpu_baseline(args.cpu_seconds, sd)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
