@@ -490,7 +490,7 @@ def testset_bench(args, net, dev, rank, world, dist):
         flop = float(len(poses)) * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
         peak = (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS) * world
         achieved = flop * args.steps / elapsed / 1e12
-        print(json.dumps({
+        line = {
             "metric": "rays/sec (%d-view test set, 800x800, 64 coarse + 128 fine samples/ray%s)" % (len(poses), ", bf16 MLP" if bf16 else ""),
             "value": len(poses) * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps / len(poses),
@@ -500,8 +500,10 @@ def testset_bench(args, net, dev, rank, world, dist):
                                    % (len(poses), world, args.dtype), "views": len(poses), "rays_per_frame": R,
                        "views_per_rank": len(mine)},
             "roofline": {"kernel": "whole job (MLP FLOPs of all views / wall time / (peak x ranks))", "bound": "mfma",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}}),
-            flush=True)
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -548,7 +550,7 @@ def frame_bench(args, net, dev, rank, world, dist):
         flop = float(R) * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
         peak = (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS) * world
         achieved = flop * args.steps / elapsed / 1e12
-        print(json.dumps({
+        line = {
             "metric": "rays/sec (one 800x800 frame ray-sharded over the GPUs, 64 coarse + 128 fine samples/ray%s)" % (", bf16 MLP" if bf16 else ""),
             "value": R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps,
@@ -558,8 +560,10 @@ def frame_bench(args, net, dev, rank, world, dist):
                                    "%d rank(s), outputs all-gathered on every rank, %s MLP" % (world, args.dtype),
                        "rays_per_frame": R, "rays_per_rank": -(-R // world), "gather_bytes_per_ray": 36},
             "roofline": {"kernel": "whole step (MLP FLOPs of the frame / wall time / (peak x ranks))", "bound": "mfma",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}}),
-            flush=True)
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
