@@ -91,19 +91,20 @@ __device__ __forceinline__ int route_cell(const Grid& g, float x, float y, float
 // touches only a dozen cells: a block owns one chunk, histograms it in LDS and sends one global atomic per touched
 // cell (a grid-stride block would see every occupied cell and send ~900).
 constexpr int kSortChunk = 4096;
-// the routing kernel keeps nothing per point in registers, so its chunk can be larger: zeroing and flushing the
-// 4096-entry LDS histogram costs a block as much as routing 4096 points
-constexpr int kRouteChunk = 16384;
-__global__ __launch_bounds__(256) void kilo_route_kernel(Grid g, const float* __restrict__ pts, int64_t n,
+// the routing kernel keeps nothing per point in registers, so its chunk is a run-time multiple of 256: large for a
+// frame's 27 M points (zeroing and flushing the 4096-entry LDS histogram costs a block as much as routing 4096
+// points), small for a training batch (176 k points in 16384-point chunks are 11 workgroups on 256 CUs: 14 -> 49 us)
+static int route_chunk(int64_t n) { return n >= (int64_t(1) << 22) ? 16384 : n >= (int64_t(1) << 19) ? 4096 : 1024; }
+__global__ __launch_bounds__(256) void kilo_route_kernel(Grid g, const float* __restrict__ pts, int64_t n, int chunk,
                                                          int* __restrict__ cell, int* __restrict__ hist) {
     extern __shared__ int s_hist[];
     const int ncell = g.res[0] * g.res[1] * g.res[2];
     if (hist)
         for (int i = threadIdx.x; i < ncell; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
-    const int64_t begin = int64_t(blockIdx.x) * kRouteChunk;
+    const int64_t begin = int64_t(blockIdx.x) * chunk;
     const int lane = threadIdx.x & 63;
-    for (int k = 0; k < kRouteChunk / 256; ++k) {  // every lane runs every round: the run detection needs full waves
+    for (int k = 0; k < chunk / 256; ++k) {  // every lane runs every round: the run detection needs full waves
         const int64_t i = begin + k * 256 + threadIdx.x;
         const bool in = i < n;
         int c = -1;
@@ -576,10 +577,11 @@ NRF_EXPORT int nrf_kilo_route(const float* pts, int64_t n, const float* aabb_hos
     if (!pts || !aabb_host || !res_host || !cell) return NRF_ERR_NULL;
     const Grid g = make_grid(aabb_host, res_host);
     if (g.res[0] <= 0 || g.res[1] <= 0 || g.res[2] <= 0) return NRF_ERR_SHAPE;
-    const int64_t blocks = (n + kRouteChunk - 1) / kRouteChunk;   // one contiguous chunk per block
+    const int chunk = route_chunk(n);
+    const int64_t blocks = (n + chunk - 1) / chunk;   // one contiguous chunk per block
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
     nrf_launch_begin();
-    kilo_route_kernel<<<dim3(unsigned(blocks)), 256, 0, static_cast<hipStream_t>(stream)>>>(g, pts, n, cell, nullptr);
+    kilo_route_kernel<<<dim3(unsigned(blocks)), 256, 0, static_cast<hipStream_t>(stream)>>>(g, pts, n, chunk, cell, nullptr);
     return nrf_launch_status();
 }
 
@@ -611,8 +613,9 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
     nrf_launch_begin();
     (void)hipMemsetAsync(hist, 0, size_t(num_cells + 1) * 4, stream);
     const unsigned rb = unsigned((n_points + kSortChunk - 1) / kSortChunk);   // n_points <= 2^28: at most 65536 blocks
-    kilo_route_kernel<<<dim3(unsigned((n_points + kRouteChunk - 1) / kRouteChunk)), 256, size_t(num_cells) * 4, stream>>>(
-        g, pts, n_points, cell, hist);
+    const int rchunk = route_chunk(n_points);
+    kilo_route_kernel<<<dim3(unsigned((n_points + rchunk - 1) / rchunk)), 256, size_t(num_cells) * 4, stream>>>(
+        g, pts, n_points, rchunk, cell, hist);
     // tiles of one cell per weight load: up to kJobTiles, fewer for small batches so that every wavefront gets jobs
     int64_t jt = (n_points + 32 * 4 * int64_t(cus) * 4 - 1) / (32 * 4 * int64_t(cus) * 4);
     const int job_tiles = int(jt < 4 ? 4 : jt > kJobTiles ? kJobTiles : jt);
