@@ -27,6 +27,16 @@ def view_schedule(n_views: int, rank: int, world: int, tiles_per_view: int = 1):
     return items[rank::world]
 
 
+def _all_reduce(t: torch.Tensor, op, group=None) -> None:
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":              # rehearsal / CPU-only transport: stage through host
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 def allreduce_gradients(flat_grad: torch.Tensor, group=None) -> float:
     """Data-parallel gradient exchange of the training steps (``trainer.py:14-21`` DDP semantics: every rank has
     its own batch, parameters move by the MEAN gradient): ONE sum all-reduce of the flat gradient buffer (RCCL
@@ -38,23 +48,8 @@ def allreduce_gradients(flat_grad: torch.Tensor, group=None) -> float:
         return 1.0
     world = dist.get_world_size(group)
     if world > 1:
-        if flat_grad.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal / CPU-only transport: stage through host
-            host = flat_grad.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            flat_grad.copy_(host)
-        else:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(flat_grad, dist.ReduceOp.SUM, group)
     return 1.0 / world
-
-
-def _all_reduce(t: torch.Tensor, op, group=None) -> None:
-    import torch.distributed as dist
-    if t.is_cuda and dist.get_backend(group) == "gloo":              # rehearsal / CPU-only transport
-        host = t.cpu()
-        dist.all_reduce(host, op=op, group=group)
-        t.copy_(host)
-    else:
-        dist.all_reduce(t, op=op, group=group)
 
 
 def allreduce_cell_gradients(grads, touched: torch.Tensor, group=None) -> float:
