@@ -4,19 +4,26 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Either form runs N ranks, one per GPU, on RCCL (backend "nccl"): started plainly with N > 1 this file spawns the
+ranks itself before any GPU call (launch_ranks); under torch.distributed.run it takes the world from the environment
+and insists that it equals --gpus.  `n_gpus` in the line is the process group's own world size.
+
 A *step* is one full 800x800 test-view render (BASELINE.json configs[1]: NeRF coarse + fine,
 fp32 MLP, random-init weights, synthetic orbit camera): ray generation -> coarse MLP ->
 compositing -> importance resampling + merge -> fine MLP -> compositing, everything on the
-GPU, inputs (pose, weights) resident before the timed region.  With N ranks every rank
-renders its own view per step (views of the 200-view orbit are sharded round-robin, no
-data-path collective): weak scaling, value = all rays of all ranks / max-over-ranks time.
+GPU, inputs (pose, weights) resident before the timed region.  With N > 1 ranks the view's rays are
+split in contiguous slices over the ranks and one all_gather assembles the frame on every rank:
+value = rays of the frame / max-over-ranks time per frame (strong scaling, the metric's "ms per
+800x800 frame at 1/2/4/8 MI355X"); the one-view-per-rank rate is carried as `weak_scaling`.
 
 The same JSON line carries
   roofline      the dominant kernel (mlp_fwd_kernel, MFMA-bound): algorithmic FLOPs per launch
                 / its mean launch time, measured with HIP events on the launch stream inside
                 the timed region; peak = fp32 MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md)
   cpu_baseline  oracle/ (the CPU restatement of the reference) timed on this host's cores
-                on a bounded sample of the same rays (rank 0, N=1 only).
+                on a bounded sample of the same rays (rank 0, N=1 only)
+  also          (N=1) BASELINE configs[4] per-view form (bf16 MLP), configs[2] (training step) and
+                configs[3] (KiloNeRF frame), measured in the same process after the headline.
 """
 import argparse
 import json
@@ -39,18 +46,22 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF de
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="number of ranks = GPUs.  Started plainly (no RANK / WORLD_SIZE in the environment) with N > 1, "
+                         "bench.py spawns the N ranks itself before anything touches a GPU; under torch.distributed.run it "
+                         "must equal WORLD_SIZE")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default="render", choices=["render", "train", "kilo", "kilo_train", "testset", "frame"],
-                    help="render: BASELINE configs[1] (default, the headline metric); train: configs[2], "
-                         "4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce; kilo: configs[3], KiloNeRF "
-                         "800x800 frame with the sphere occupancy grid; kilo_train: KiloNeRF distillation step (SURVEY 8f rank 3); testset: configs[4], the 200-view test set "
-                         "dealt round-robin over the ranks (strong scaling; a step = one pass over all views, a warm-up step = one "
-                         "view per rank; use with --dtype bf16); frame: one view per step, its rays in contiguous slices over the ranks + one "
-                         "all_gather (strong scaling, the latency form of the metric)")
+                    help="render: BASELINE configs[1] (default, the headline metric; with N > 1 ranks the headline is ONE view "
+                         "per step ray-sharded over the ranks and the one-view-per-rank rate is carried as `weak_scaling`); "
+                         "train: configs[2], 4096-ray fwd+bwd+Adam step per rank with one RCCL gradient all-reduce; kilo: "
+                         "configs[3], KiloNeRF 800x800 frame with the sphere occupancy grid; kilo_train: KiloNeRF distillation "
+                         "step (SURVEY 8f rank 3); testset: configs[4], the 200-view test set dealt round-robin over the ranks "
+                         "(strong scaling; a step = one pass over all views, a warm-up step = one view per rank; use with "
+                         "--dtype bf16); frame: the ray-sharded headline of `render` alone, without per-stage events")
     ap.add_argument("--views", type=int, default=200, help="testset mode: number of views in the set")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="render mode only: fp32 = BASELINE configs[1] (the headline metric); bf16 = the bf16 MLP of "
@@ -58,14 +69,18 @@ def parse():
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--no-also", action="store_true",
+                    help="render mode, 1 GPU: skip the `also` block (bf16 frame, training step, KiloNeRF frame measured in "
+                         "the same process after the headline)")
+    return ap.parse_args(argv)
 
 
-def recorded_traffic():
-    """HBM bytes per mlp_fwd_kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_mlp_traffic_pmc.json: FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md corrections).  Counters cannot
-    be read from inside the process, so this is the recorded figure, or None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_mlp_traffic_pmc.json")
+def recorded_traffic(bf16: bool = False):
+    """HBM bytes per MLP launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE,
+    MI355X_MICROARCH.md corrections): profiles/r01_mlp_traffic_pmc.json (mlp_fwd_kernel) or
+    profiles/r02_bf16_traffic_pmc.json (mlp_bf16_kernel).  Counters cannot be read from inside the process, so this is
+    the recorded figure, or None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r02_bf16_traffic_pmc.json" if bf16 else "r01_mlp_traffic_pmc.json")
     try:
         with open(path) as f:
             return float(json.load(f)["traffic_bytes_per_launch_mean"])
@@ -199,10 +214,8 @@ def train_bench(args, net, dev, rank, world, dist):
             "final_loss": loss}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = train_cpu_baseline(args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 def kilo_cpu_baseline(seconds: float, sd, frame_samples: float):
@@ -318,10 +331,8 @@ def kilo_bench(args, dev, rank, world, dist):
             "stage_ms": ms}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = kilo_cpu_baseline(args.cpu_seconds, sd, n)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 def kilo_train_cpu_baseline(seconds: float, sd, rays_per_step: int = 256):
@@ -436,10 +447,8 @@ def kilo_train_bench(args, dev, rank, world, dist):
             "final_loss": loss}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = kilo_train_cpu_baseline(args.cpu_seconds, sd)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 def testset_bench(args, net, dev, rank, world, dist):
@@ -503,28 +512,51 @@ def testset_bench(args, net, dev, rank, world, dist):
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return line
+    return None
 
 
-def frame_bench(args, net, dev, rank, world, dist):
-    """Latency form of BASELINE configs[1] / the metric's "ms per 800x800 frame at 1/2/4/8 MI355X": ONE view per step,
-    its 640,000 rays split in contiguous slices over the ranks (Renderer.render_view_sharded), one all_gather of the
-    per-ray outputs so every rank ends the step holding the whole frame.  Strong scaling: the frame is fixed."""
+def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, warmup=None, staged=True, cpu=True):
+    """The headline (BASELINE configs[1], or configs[4]'s per-view form with dtype bf16).  A step = ONE 800x800 view:
+    with one rank the whole frame on that GPU; with N ranks the view's 640,000 rays in contiguous slices over the ranks
+    (north star: "rays/image tiles are sharded"), every rank generating its own rays from the pose, and one all_gather
+    of 36 B per ray so every rank ends the step holding the whole frame (strong scaling: ms per frame at N GPUs).
+    With N > 1 the one-view-per-rank rate (no collective) is measured after it and carried as `weak_scaling`."""
+    from nerf_amd import ops
     from nerf_amd.camera import test_set_poses, focal_from_angle
     from nerf_amd.config import default_cfg
+    from nerf_amd.parallel import render_frame_sharded
     from nerf_amd.renderer import Renderer
-    renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=args.dtype)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=dtype)
+    bf16 = dtype == "bf16"
+    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
     R = H * W
+    events = {}
     gen = torch.Generator(device=dev)
-    gen.manual_seed(4321 + rank)
+    gen.manual_seed(1234 + rank)
+    keys = ("coarse_rgb_map", "coarse_depth_map", "fine_rgb_map", "fine_depth_map", "alpha_map")
 
-    def step(k):
-        return renderer.render_view_sharded(poses[k % len(poses)], H, W, focal, rank, world, dev, gather=True, generator=gen)[0]
+    def rows(c2w, ev):
+        def render(first, count):
+            rays_o, rays_d = ops.raygen(c2w, H, W, focal, dev, first_ray=first, n_rays=count)
+            u = torch.rand((count, N_IMPORTANCE), device=dev, generator=gen)
+            u2 = torch.rand((count, N_IMPORTANCE), device=dev, generator=gen)
+            if staged:
+                out = renderer.render_rays_staged(rays_o, rays_d, u, u2, events=ev)
+            else:
+                out = renderer.render_rays(rays_o, rays_d, u, u2)
+            return {k: out[k] for k in keys}
+        return render
+
+    def frame_step(k, ev):          # one view, ray-sharded over the ranks, assembled on every rank
+        return render_frame_sharded(rows(poses[k % len(poses)], ev), R, rank, world, gather=True)[0]
+
+    def view_step(k, ev):           # one view per rank, no collective
+        return rows(poses[(k * world + rank) % len(poses)], ev)(0, R)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -532,72 +564,244 @@ def frame_bench(args, net, dev, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        out = step(k)
+    def timed(step, ev):
+        with torch.no_grad():
+            for k in range(warmup):
+                out = step(k, None)
+            sync()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                out = step(warmup + k, ev)
+            sync()
+            elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert out["fine_rgb_map"].shape == (R, 3) and torch.isfinite(out["fine_rgb_map"]).all()
+        return elapsed
+
+    elapsed = timed(frame_step, events if staged else None)
+    weak = None
+    if world > 1:
+        el_w = timed(view_step, None)
+        weak = {"value": world * R * steps / el_w, "unit": "rays/s", "ms_per_step": 1e3 * el_w / steps, "scaling": "weak",
+                "note": "every rank renders its own 800x800 view per step (views of the 200-view orbit dealt round-robin), "
+                        "no data-path collective"}
+    if rank != 0:
+        return None
+    ms_step = 1e3 * elapsed / steps
+    mine = -(-R // world)                                      # rays of rank 0's slice (the largest)
+    line = {
+        "metric": "rays/sec (full 800x800 frame, 64 coarse + 128 fine samples/ray)" + (", bf16 MLP" if bf16 else ""),
+        "value": R * steps / elapsed,
+        "unit": "rays/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_step,
+        "ms_per_frame": ms_step,
+        "higher_is_better": True,
+        "scaling": "weak" if world == 1 else "strong",
+        "vs_baseline": None,
+        "dtype": "bf16" if bf16 else "f32",
+        "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
+        "config": {"workload": ("BASELINE configs[4] per-view form: full 800x800 test-view render, NeRF coarse+fine, bf16 MLP "
+                                "(bf16 weights + activations, fp32 accumulate), " if bf16 else
+                                "BASELINE configs[1]: full 800x800 lego test-view render, NeRF coarse+fine, fp32, ") +
+                               ("one view per step on one GPU" if world == 1 else
+                                "one view per step, its rays in contiguous slices over %d ranks, outputs all-gathered on "
+                                "every rank" % world),
+                   "rays_per_frame": R, "n_coarse": N_COARSE, "n_importance": N_IMPORTANCE, "rays_per_rank": mine,
+                   "sharding": ("whole frame on one GPU" if world == 1 else
+                                f"contiguous ray slices of one view over {world} ranks + one all_gather of 36 B/ray")},
+    }
+    if weak is not None:
+        line["weak_scaling"] = weak
+    if staged:
+        def mean_ms(name):
+            return float(np.mean([a.elapsed_time(b) for a, b in events[name]]))
+
+        ms_mlp_c, ms_mlp_f = mean_ms("mlp_coarse"), mean_ms("mlp_fine")
+        ms_cmp_c, ms_cmp_f, ms_smp = mean_ms("composite_coarse"), mean_ms("composite_fine"), mean_ms("sample_fine")
+        flop_launch = 0.5 * mine * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT   # mean of the 2 launches
+        ms_launch = 0.5 * (ms_mlp_c + ms_mlp_f)
+        achieved = flop_launch / (ms_launch * 1e-3) / 1e12
+        cmp_bytes = mine * ((N_COARSE + N_IMPORTANCE) * 20 + 20)
+        whole = world == 1
+        line["roofline"] = {
+            "kernel": "mlp_bf16_kernel (fused points + PE + 8x256 MLP, bf16 MFMA)" if bf16 else
+                      "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": recorded_traffic(bf16) if whole else None,
+            "traffic_note": "HBM bytes per launch (mean of coarse + fine) from the committed rocprofv3 PMC passes of this "
+                            "command at 1 GPU (profiles/); algorithmic bytes per launch %.4g"
+                            % (0.5 * mine * ((N_COARSE + N_COARSE + N_IMPORTANCE) * 16 + 48 + (N_COARSE + N_IMPORTANCE) * 4)),
+            "flop_per_launch": flop_launch, "ms_per_launch": ms_launch,
+            "ms_coarse_launch": ms_mlp_c, "ms_fine_launch": ms_mlp_f, "measured_on": "rank 0, HIP events on the launch stream"}
+        line["roofline_composite"] = {
+            "kernel": "composite_kernel<3> (fine pass)", "bound": "hbm",
+            "achieved": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": recorded_composite_traffic() if whole else None, "ms_per_launch": ms_cmp_f,
+            "bytes_per_launch": cmp_bytes}
+        line["stage_ms"] = {"mlp_coarse": ms_mlp_c, "composite_coarse": ms_cmp_c, "sample_fine": ms_smp,
+                            "mlp_fine": ms_mlp_f, "composite_fine": ms_cmp_f}
+    else:
+        flop = float(R) * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
+        achieved = flop * steps / elapsed / 1e12
+        line["roofline"] = {"kernel": "whole step (MLP FLOPs of the frame / wall time / (peak x ranks))", "bound": "mfma",
+                            "achieved": achieved, "peak": peak * world, "unit": "TFLOP/s", "frac": achieved / (peak * world),
+                            "traffic": None}
+    if cpu and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    return line
+
+
+def also_block(args, net, dev):
+    """BASELINE configs[4] (per-view form), configs[2] and configs[3] under the same clock as the headline: measured in
+    this process right after it, one GPU, no CPU legs.  Each entry is a cut of the line its own --mode prints."""
+    def cut(line):
+        return {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+                "steps": line["steps"], "warmup": line["warmup"], "dtype": line["dtype"],
+                "workload": line["config"]["workload"],
+                "roofline": {k: line["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}}
+
+    sub = argparse.Namespace(**vars(args))
+    sub.no_cpu_baseline = True
+    out = {}
+    out["bf16_frame"] = cut(render_bench(sub, net, dev, 0, 1, None, dtype="bf16", steps=5, warmup=1, cpu=False))
+    torch.cuda.empty_cache()
+    sub.steps, sub.warmup = 20, 3
+    out["train_step"] = cut(train_bench(sub, copy_network(net, dev), dev, 0, 1, None))
+    torch.cuda.empty_cache()
+    sub.steps, sub.warmup = 20, 3
+    out["kilo_frame"] = cut(kilo_bench(sub, dev, 0, 1, None))
+    torch.cuda.empty_cache()
+    return out
+
+
+def copy_network(net, dev):
+    """TrainStep re-points a network's parameters at its flat buffer: give it a copy, not the bench's network."""
+    from nerf_amd.network import Network
+    twin = Network()
+    twin.load_state_dict(net.state_dict())
+    return twin.to(dev)
+
+
+# ---- ranks ------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` started plainly: this process touches no GPU (torch.cuda.device_count() does not
+    initialise one here) and starts N children of this same file, one rank per GPU, with the env:// rendezvous
+    variables torch.distributed.run would set (the reference's launch contract: train.py:116-120 reads LOCAL_RANK and
+    calls init_process_group("nccl", "env://")).  Rank 0's stdout carries the JSON line.  A rank that fails ends the
+    others (by their PIDs) and its exit code is ours."""
+    import socket
+    import subprocess
+    n = args.gpus
+    backend = os.environ.get("NRF_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not DRY_RUN and torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {torch.cuda.device_count()} GPU(s); RCCL needs one GPU per "
+                         "rank (NRF_BENCH_BACKEND=gloo rehearses more ranks than GPUs)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env))
+    code = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and code == 0:
+                code = rc
+                for q in live:
+                    q.terminate()
+    return code
+
+
+DRY_RUN = os.environ.get("NRF_BENCH_DRY_RUN", "") == "1"
+
+
+def dry_run(args, rank, world, dist):
+    """NRF_BENCH_DRY_RUN=1: the launch / rendezvous / barrier / max-over-ranks plumbing with an empty step, for hosts
+    without a GPU (tests/test_bench_launch.py).  It measures nothing and says so: value is null."""
+    def sync():
+        if dist is not None:
+            dist.barrier()
+
     sync()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        out = step(args.warmup + k)
+    for _ in range(args.steps):
+        pass
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert out["fine_rgb_map"].shape == (R, 3) and torch.isfinite(out["fine_rgb_map"]).all()
-    if rank == 0:
-        bf16 = args.dtype == "bf16"
-        flop = float(R) * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
-        peak = (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS) * world
-        achieved = flop * args.steps / elapsed / 1e12
-        line = {
-            "metric": "rays/sec (one 800x800 frame ray-sharded over the GPUs, 64 coarse + 128 fine samples/ray%s)" % (", bf16 MLP" if bf16 else ""),
-            "value": R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
-            "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
-            "config": {"workload": "BASELINE configs[1] latency form: one 800x800 view per step, rays in contiguous slices over "
-                                   "%d rank(s), outputs all-gathered on every rank, %s MLP" % (world, args.dtype),
-                       "rays_per_frame": R, "rays_per_rank": -(-R // world), "gather_bytes_per_ray": 36},
-            "roofline": {"kernel": "whole step (MLP FLOPs of the frame / wall time / (peak x ranks))", "bound": "mfma",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if rank != 0:
+        return None
+    return {"metric": "dry run (no GPU work: launcher and rendezvous only)", "value": None, "unit": "rays/s",
+            "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "dry_run": True, "mode": args.mode,
+            "backend": dist.get_backend() if dist is not None else None}
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start it plainly (it spawns its own ranks) "
+                         "or give torch.distributed.run the same --nproc-per-node")
+    # One rank per GPU on RCCL (backend "nccl").  NRF_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs
+    # than ranks (ranks then share devices and the collectives are staged through the host); it is never the measured
+    # configuration and the line says which backend ran.
+    backend = os.environ.get("NRF_BENCH_BACKEND", "nccl")
+    dist = None
+    if DRY_RUN:
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo", init_method="env://")
+        line = dry_run(args, rank, world, dist)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+        if backend != "nccl":
+            local %= torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            import torch.distributed as dist
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+            else:
+                dist.init_process_group(backend=backend, init_method="env://")
+            world = dist.get_world_size()                       # what the process group itself reports
+        line = run_mode(args, dev, rank, world, dist)
+        if line is not None and dist is not None:
+            line["backend"] = dist.get_backend() + (" (= RCCL over xGMI)" if dist.get_backend() == "nccl" else
+                                                    " (rehearsal: ranks share GPUs, collectives staged through the host)")
+    if line is not None:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    # One rank per GPU.  NRF_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks (ranks then
-    # share devices and the timing collectives run over gloo); the measured configuration is always nccl = RCCL.
-    backend = os.environ.get("NRF_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local %= torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend, init_method="env://")
-
-    from nerf_amd import ops
-    from nerf_amd.camera import test_set_poses, focal_from_angle
-    from nerf_amd.config import default_cfg
+def run_mode(args, dev, rank, world, dist):
     from nerf_amd.network import Network
-    from nerf_amd.renderer import Renderer
     from nerf_amd.weights import make_state_dict
-
     if args.mode == "kilo":
         return kilo_bench(args, dev, rank, world, dist)
     if args.mode == "kilo_train":
@@ -610,96 +814,11 @@ def main():
     if args.mode == "testset":
         return testset_bench(args, net, dev, rank, world, dist)
     if args.mode == "frame":
-        return frame_bench(args, net, dev, rank, world, dist)
-    renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=args.dtype)
-    bf16 = args.dtype == "bf16"
-    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
-    poses = test_set_poses(200)
-    focal = focal_from_angle(W)
-    R = H * W
-    events = {}
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-
-    def step(k, ev):
-        c2w = poses[(k * world + rank) % len(poses)]
-        rays_o, rays_d = ops.raygen(c2w, H, W, focal, dev)
-        u = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
-        u2 = torch.rand((R, N_IMPORTANCE), device=dev, generator=gen)
-        return renderer.render_rays_staged(rays_o, rays_d, u, u2, events=ev)
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    with torch.no_grad():
-        for k in range(args.warmup):
-            out = step(k, None)
-        sync()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            out = step(args.warmup + k, events)
-        sync()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out["fine_rgb_map"]).all()
-
-    def mean_ms(name):
-        return float(np.mean([a.elapsed_time(b) for a, b in events[name]]))
-
-    ms_mlp_c, ms_mlp_f = mean_ms("mlp_coarse"), mean_ms("mlp_fine")
-    ms_cmp_c, ms_cmp_f, ms_smp = mean_ms("composite_coarse"), mean_ms("composite_fine"), mean_ms("sample_fine")
-    if rank == 0:
-        ms_step = 1e3 * elapsed / args.steps
-        flop_launch = 0.5 * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT   # mean of the 2 launches
-        ms_launch = 0.5 * (ms_mlp_c + ms_mlp_f)
-        achieved = flop_launch / (ms_launch * 1e-3) / 1e12
-        cmp_bytes = R * ((N_COARSE + N_IMPORTANCE) * 20 + 20)
-        line = {
-            "metric": "rays/sec (full 800x800 frame, 64 coarse + 128 fine samples/ray)" + (", bf16 MLP" if bf16 else ""),
-            "value": world * R * args.steps / elapsed,
-            "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step,
-            "ms_per_frame": ms_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16" if bf16 else "f32",
-            "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
-            "config": {"workload": ("BASELINE configs[4] per-view form: full 800x800 test-view render, NeRF coarse+fine, bf16 MLP "
-                                    "(bf16 weights + activations, fp32 accumulate), " if bf16 else
-                                    "BASELINE configs[1]: full 800x800 lego test-view render, NeRF coarse+fine, fp32, ") +
-                                   "one view per rank per step", "rays_per_frame": R, "n_coarse": N_COARSE,
-                       "n_importance": N_IMPORTANCE, "sharding": f"views round-robin over {world} rank(s)"},
-            "roofline": {"kernel": "mlp_bf16_kernel (fused points + PE + 8x256 MLP, bf16 MFMA)" if bf16 else
-                                   "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
-                         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None if bf16 else recorded_traffic(),
-                         "traffic_note": "HBM bytes per launch (mean of coarse + fine) from profiles/r01_mlp_traffic_pmc.json; "
-                                         "algorithmic bytes per launch %.4g" % (0.5 * R * ((N_COARSE + N_COARSE + N_IMPORTANCE) * 16
-                                                                                        + 48 + (N_COARSE + N_IMPORTANCE) * 4)),
-                         "flop_per_launch": flop_launch, "ms_per_launch": ms_launch,
-                         "ms_coarse_launch": ms_mlp_c, "ms_fine_launch": ms_mlp_f},
-            "roofline_composite": {"kernel": "composite_kernel<3> (fine pass)", "bound": "hbm",
-                                   "achieved": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "traffic": recorded_composite_traffic(), "ms_per_launch": ms_cmp_f,
-                                   "bytes_per_launch": cmp_bytes},
-            "stage_ms": {"mlp_coarse": ms_mlp_c, "composite_coarse": ms_cmp_c, "sample_fine": ms_smp,
-                         "mlp_fine": ms_mlp_f, "composite_fine": ms_cmp_f},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return render_bench(args, net, dev, rank, world, dist, dtype=args.dtype, staged=False)
+    line = render_bench(args, net, dev, rank, world, dist, dtype=args.dtype)
+    if line is not None and world == 1 and args.dtype == "fp32" and not args.no_also:
+        line["also"] = also_block(args, net, dev)
+    return line
 
 
 if __name__ == "__main__":

@@ -32,7 +32,9 @@ typedef enum nrf_status {
     NRF_ERR_SHAPE = -2,      /* a size is outside what the kernels support */
     NRF_ERR_LAUNCH = -3,     /* hipGetLastError() reported a launch failure */
     NRF_ERR_WORKSPACE = -4,  /* workspace too small */
-    NRF_ERR_ALIGN = -5       /* a pointer is not 16-byte aligned */
+    NRF_ERR_ALIGN = -5,      /* a pointer is not 16-byte aligned */
+    NRF_ERR_STATIC_LIMIT = -6, /* nrf_render_static: more rays / samples than the static scratch holds */
+    NRF_ERR_RUNTIME = -7     /* a HIP runtime query failed (hipGetDevice, hipGetSymbolAddress) */
 } nrf_status;
 
 /* Layer order used by every `w[12]` / `b[12]` argument: the reference's state-dict layout
@@ -302,6 +304,19 @@ int nrf_render(const nrf_render_args* args, nrf_stream_t stream);
 /* The same path with bf16 MLPs: packed_coarse / packed_fine are nrf_pack_weights_bf16 streams (cast to const float*),
  * everything else as above (compositing, resampling and all outputs stay fp32). */
 int nrf_render_bf16(const nrf_render_args* args, nrf_stream_t stream);
+
+
+/* ---- the whole forward path without any allocation ------------------------------------------------------------------
+ * No counterpart in the reference (its renderer allocates through torch at every op).  For callers that cannot
+ * allocate or pass scratch: code under HIP graph capture, serving loops with a frozen allocator, harnesses that forbid
+ * hipMalloc.  Same enqueue sequence and results as nrf_render (fp32 MLPs), but args->workspace / workspace_bytes are
+ * IGNORED: the workspace is a device array inside the library, sized for NRF_RENDER_STATIC_MAX_RAYS rays (the
+ * reference's chunk_size) at up to 256 samples per ray = 23.1 MB per GPU the library runs on, held until the process
+ * ends.  More rays or samples -> NRF_ERR_STATIC_LIMIT (split the batch, or use nrf_render).  Calls no hipMalloc /
+ * hipFree / allocating routine.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two
+ * streams, two threads) race; serialise them.  Inputs and outputs are the caller's, as in nrf_render. */
+#define NRF_RENDER_STATIC_MAX_RAYS 4096
+int nrf_render_static(const nrf_render_args* args, nrf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ SYMBOLS = (
     "nrf_kilo_packed_bwd_floats", "nrf_kilo_pack_weights_transposed", "nrf_kilo_composite_backward",
     "nrf_kilo_backward_workspace_bytes", "nrf_kilo_backward", "nrf_l2_reg",
     "nrf_kilo_record_floats", "nrf_kilo_cells_gather", "nrf_kilo_cells_scatter",
+    "nrf_render_static",
 )
 
 P = C.c_void_p
@@ -79,6 +80,8 @@ def lib() -> C.CDLL:
     L.nrf_render.argtypes = [C.POINTER(RenderArgs), P]
     L.nrf_render_bf16.argtypes = [C.POINTER(RenderArgs), P]
     L.nrf_render_bf16.restype = INT
+    L.nrf_render_static.argtypes = [C.POINTER(RenderArgs), P]
+    L.nrf_render_static.restype = INT
     L.nrf_packed_bwd_floats.restype = I64
     L.nrf_pack_weights_transposed.argtypes = [P, P, P]
     for name in ("nrf_mlp_train_tiles", "nrf_mlp_acts_bytes", "nrf_mlp_masks_bytes", "nrf_mlp_backward_workspace_bytes"):

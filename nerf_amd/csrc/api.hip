@@ -2,6 +2,8 @@
 // (the intended body of Renderer.forward, volume_renderer.py:143-153) as one enqueue sequence.
 #include "nrf_common.h"
 
+#include <atomic>
+
 NRF_EXPORT int nrf_version(void) { return 100; }
 
 NRF_EXPORT const char* nrf_strerror(int status) {
@@ -12,17 +14,21 @@ NRF_EXPORT const char* nrf_strerror(int status) {
         case NRF_ERR_LAUNCH: return "HIP kernel launch failed";
         case NRF_ERR_WORKSPACE: return "workspace too small (see nrf_render_workspace_bytes)";
         case NRF_ERR_ALIGN: return "pointer not 16-byte aligned";
+        case NRF_ERR_STATIC_LIMIT:
+            return "nrf_render_static: n_rays or sample count beyond the library's static scratch "
+                   "(NRF_RENDER_STATIC_MAX_RAYS rays, n_coarse + n_importance <= 256); use nrf_render with a workspace";
+        case NRF_ERR_RUNTIME: return "a HIP runtime call failed (hipGetDevice / hipGetSymbolAddress)";
         default: return "unknown nrf_status";
     }
 }
 
 namespace {
 
-inline int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
+constexpr int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
 
 struct Workspace {
-    int64_t raw, z_coarse, w_coarse, acc_coarse, z_fine, total;
-    Workspace(int64_t R, int nc, int ni) {
+    int64_t raw = 0, z_coarse = 0, w_coarse = 0, acc_coarse = 0, z_fine = 0, total = 0;
+    constexpr Workspace(int64_t R, int nc, int ni) {
         int64_t off = 0;
         raw = off; off += align256(R * (nc + ni) * 4 * 4);   // raw (R, S, 4), sized for the fine pass
         z_coarse = off; off += align256(R * nc * 4);         // only used when perturbed
@@ -90,3 +96,39 @@ NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) { retur
 // Same path with both MLPs evaluated by nrf_mlp_forward_rays_bf16: packed_coarse / packed_fine point at
 // nrf_pack_weights_bf16 streams (BASELINE configs[4]).
 NRF_EXPORT int nrf_render_bf16(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, true, stream); }
+
+// ---- nrf_render without an allocation anywhere (no counterpart in the reference) ---------------------------------------
+// nrf_render's kernels need a workspace (raw, coarse weights, depths: ~4.4 KB per ray) that the caller normally brings.
+// Callers that cannot allocate (HIP graph capture, serving loops with a frozen allocator, harnesses that forbid
+// hipMalloc) get the same enqueue sequence over a file-scope device array instead: kStaticBytes per GPU the library
+// runs on, held until the process ends.  `scratch` below is only the host-side stand-in of that array; its device
+// address is asked for once per device (hipGetSymbolAddress with that device current: every GPU has its own copy at
+// its own address) and only that pointer is ever handed to kernels.
+namespace {
+constexpr int kStaticMaxRays = NRF_RENDER_STATIC_MAX_RAYS;
+constexpr int64_t kStaticBytes = Workspace(kStaticMaxRays, 64, 192).total;
+constexpr int kMaxDevices = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+static std::atomic<void*> g_scratch_ptr[kMaxDevices];
+
+NRF_EXPORT int nrf_render_static(const nrf_render_args* a, nrf_stream_t stream) {
+    if (!a) return NRF_ERR_NULL;
+    if (a->n_rays > kStaticMaxRays || a->n_coarse + (int64_t)a->n_importance > 256) return NRF_ERR_STATIC_LIMIT;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return NRF_ERR_RUNTIME;
+    void* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {   // first call on this device (two threads racing here both get the same address)
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return NRF_ERR_RUNTIME;
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    nrf_render_args b = *a;
+    b.workspace = ptr;
+    b.workspace_bytes = kStaticBytes;
+    // Every workspace region is fully written by the stage that produces it before the stage that reads it
+    // (raw by the MLP, weights / acc by compositing, depths by the resampler), for exactly n_rays rows: nothing has
+    // to start at zero, so what the previous call left behind is never read.
+    return render_path(&b, false, stream);
+}
