@@ -259,11 +259,12 @@ def points(o: torch.Tensor, d: torch.Tensor, z: torch.Tensor):
 
 def render(sd: dict, rays_o, rays_d, near=2.0, far=6.0, n_coarse=64, n_importance=128,
            white_bkgd=True, u=None, u2=None, bins_table=None, u_coarse=None, u_fine=None,
-           return_intermediates=False):
+           return_intermediates=False, bf16=False):
     """Coarse + fine render of R rays.  ``sd``: state dict of fp32 torch CPU tensors.
 
     ``u``/``u2``: the two ``torch.rand(R, Ni)`` draws of ``importance_sampling``.
     ``u_coarse`` (R,Nc) / ``u_fine`` (R,Ni): perturbation uniforms (training, perturb>0).
+    ``bf16``: both MLPs with the rounding points of the bf16 kernel (``mlp_forward(bf16=True)``); everything else fp32.
     """
     o = torch.as_tensor(rays_o, dtype=torch.float32)
     d = torch.as_tensor(rays_d, dtype=torch.float32)
@@ -273,14 +274,14 @@ def render(sd: dict, rays_o, rays_d, near=2.0, far=6.0, n_coarse=64, n_importanc
     zc = bins if u_coarse is None else perturb(bins, u_coarse)
     zc_t = torch.from_numpy(np.ascontiguousarray(zc))
     pts, dhat = points(o, d, zc_t)
-    raw_c = network_forward(sd, pts, dhat)
+    raw_c = network_forward(sd, pts, dhat, bf16=bf16)
     rgb_c, depth_c, w_c, acc_c = composite(raw_c, zc_t, white_bkgd)
     zf, idx = importance_sampling(w_c.detach().numpy(), bins, np.asarray(u), np.asarray(u2))  # fine z carries no grad
     if u_fine is not None:
         zf = perturb(zf, u_fine)
     z_all = torch.from_numpy(merge_sort(zc, zf))
     pts_f, _ = points(o, d, z_all)
-    raw_f = network_forward(sd, pts_f, dhat, "fine")
+    raw_f = network_forward(sd, pts_f, dhat, "fine", bf16=bf16)
     rgb_f, depth_f, w_f, acc_f = composite(raw_f, z_all, white_bkgd)
     out = {
         "coarse_rgb_map": rgb_c, "coarse_depth_map": depth_c,

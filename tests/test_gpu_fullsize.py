@@ -156,3 +156,62 @@ def test_sharded_view_slices_reassemble(frame, dev):
             ref = r.render_rays(o[b:e].contiguous(), d[b:e].contiguous(), u, u2)
         for k in KEYS:
             assert torch.equal(part[k], ref[k]), k
+
+
+# ---- bf16 MLP at full size (BASELINE configs[4]: the 200-view set is 200 of these frames) -----------------------------
+@pytest.fixture(scope="module")
+def frame_bf16(dev):
+    from nerf_amd import ops
+    from nerf_amd.camera import focal_from_angle, test_set_poses
+    from nerf_amd.config import default_cfg
+    from nerf_amd.network import Network
+    from nerf_amd.renderer import Renderer
+    from nerf_amd.weights import make_state_dict
+    net = Network()
+    net.load_state_dict(make_state_dict(0, 30.0, 2.0))
+    r = Renderer(net.to(dev), default_cfg(perturb=0), mlp_dtype="bf16")
+    o, d = ops.raygen(test_set_poses(200)[57], H, W, focal_from_angle(W), dev)
+    g = torch.Generator(device=dev).manual_seed(8)
+    u = torch.rand((H * W, 128), device=dev, generator=g)
+    u2 = torch.rand((H * W, 128), device=dev, generator=g)
+    with torch.no_grad():
+        out = r.render_rays(o, d, u, u2)
+    torch.cuda.synchronize()
+    return r, o, d, u, u2, out
+
+
+@pytest.mark.parametrize("first,count", [(0, 4096), (200001, 65536), (640000 - 1000, 1000), (320000, 31)])
+def test_bf16_slices_of_the_frame_are_bit_identical(frame_bf16, first, count):
+    r, o, d, u, u2, out = frame_bf16
+    for k in KEYS:
+        assert out[k].shape[0] == H * W and torch.isfinite(out[k]).all(), k
+    sl = slice(first, first + count)
+    with torch.no_grad():
+        part = r.render_rays(o[sl].contiguous(), d[sl].contiguous(), u[sl].contiguous(), u2[sl].contiguous())
+    for k in KEYS:
+        assert torch.equal(part[k], out[k][sl]), k
+
+
+def test_bf16_full_frame_oracle_spot_check(frame_bf16):
+    """48 rays of the bf16 frame against (a) the oracle with the kernel's rounding points (bf16 weights and layer inputs,
+    fp32 accumulate: oracle.render(bf16=True)) and (b) the fp32 oracle = the reference, at the stated bf16 tolerance of
+    tests/test_gpu_bf16.py (rgb / acc 3e-3, depth 1e-2)."""
+    from nerf_amd.weights import make_state_dict
+    from oracle import nerf_oracle as O
+    r, o, d, u, u2, out = frame_bf16
+    idx = torch.linspace(0, H * W - 1, 48).long()
+    idx[:8] = torch.tensor([0, 799, 320400, 320401, 400 * 800 + 399, 639999, 200 * 800 + 400, 600 * 800 + 400])
+    sd = make_state_dict(0, 30.0, 2.0)
+    di = idx.to(o.device)
+    args = dict(u=u[di].cpu().numpy(), u2=u2[di].cpu().numpy(), bins_table=r._bins.cpu().numpy())
+    with torch.no_grad():
+        ref16 = O.render(sd, o[di].cpu().numpy(), d[di].cpu().numpy(), bf16=True, **args)
+        ref32 = O.render(sd, o[di].cpu().numpy(), d[di].cpu().numpy(), **args)
+    for k in KEYS:
+        got = out[k][di].cpu().numpy()
+        tol = 1e-2 if "depth" in k else 3e-3
+        e16 = float(np.abs(got - ref16[k].numpy().reshape(got.shape)).max())
+        e32 = float(np.abs(got - ref32[k].numpy().reshape(got.shape)).max())
+        print(f"bf16 frame spot check {k}: vs bf16 oracle {e16:.2e}, vs fp32 oracle {e32:.2e}")
+        assert e32 < tol, (k, e32)
+        assert e16 < tol, (k, e16)
