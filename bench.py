@@ -97,8 +97,11 @@ def recorded_composite_traffic():
         return None
 
 
-def cpu_baseline(seconds: float):
-    """Oracle render of 1024-ray slices of the bench view until ~`seconds` of CPU time."""
+def cpu_baseline(seconds: float, dev=None):
+    """Oracle render of 1024-ray slices of the bench view until ~`seconds` of CPU time.  With `dev`, the first slices
+    are then (untimed) rendered by the HIP path with the same uniforms and compared: the end-to-end flip report of
+    SURVEY section 7 (fine-sample bin indices that differ because the two coarse passes differ in the last bits) and
+    the rgb / depth / acc distance, in the line as `cpu_baseline.parity_check`."""
     from oracle import nerf_oracle as O
     from nerf_amd.weights import make_state_dict
     from nerf_amd.camera import pose_spherical, LEGO_CAMERA_ANGLE_X
@@ -106,20 +109,52 @@ def cpu_baseline(seconds: float):
     o, d = O.raygen(pose_spherical(0.0), H, W, LEGO_CAMERA_ANGLE_X)
     rng = np.random.Generator(np.random.PCG64(0))
     chunk, done, t0 = 1024, 0, time.perf_counter()
+    kept = []
     with torch.no_grad():
         while True:
             r0 = 400 * W + done          # central rows: rays that cross the scene box
             u = rng.random((chunk, N_IMPORTANCE), dtype=np.float32)
             u2 = rng.random((chunk, N_IMPORTANCE), dtype=np.float32)
-            O.render(sd, o[r0:r0 + chunk], d[r0:r0 + chunk], u=u, u2=u2)
+            out = O.render(sd, o[r0:r0 + chunk], d[r0:r0 + chunk], u=u, u2=u2, return_intermediates=dev is not None)
+            if dev is not None and len(kept) < 4:
+                kept.append((r0, u, u2, out))
             done += chunk
             el = time.perf_counter() - t0
             if el >= seconds or done >= 64 * chunk:
                 break
-    return {"value": done / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+    line = {"value": done / el, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{done} rays of the same 800x800 view (rows 400+), coarse+fine, oracle/nerf_oracle.py "
                       f"on torch-CPU fp32, {el:.1f} s; host has {os.cpu_count()} logical CPUs",
             "ms_per_frame_extrapolated": 1e3 * H * W * el / done}
+    if kept:
+        line["parity_check"] = parity_check(sd, o, d, kept, dev)
+    return line
+
+
+def parity_check(sd, o, d, kept, dev):
+    """HIP path vs the oracle's kept slices (the oracle is the checker here, never the thing measured)."""
+    from nerf_amd import ops
+    from nerf_amd.renderer import near_far_table
+    bins = torch.from_numpy(near_far_table(2.0, 6.0, N_COARSE)).to(dev)
+    pc, pf = ops.pack_state_dict(sd, "model", dev), ops.pack_state_dict(sd, "model_fine", dev)
+    flips = samples = 0
+    err = {"fine_rgb_map": 0.0, "fine_depth_map": 0.0, "alpha_map": 0.0}
+    for r0, u, u2, ref in kept:
+        n = u.shape[0]
+        ro, rd = torch.from_numpy(o[r0:r0 + n]).to(dev), torch.from_numpy(d[r0:r0 + n]).to(dev)
+        raw = ops.mlp_forward_rays(pc, ro, rd, bins)
+        _, _, w, _ = ops.composite(raw, bins, True, True)
+        z, _, idx = ops.sample_fine(w, bins, bins, torch.from_numpy(u).to(dev), torch.from_numpy(u2).to(dev), want_debug=True)
+        rgb, depth, _, acc = ops.composite(ops.mlp_forward_rays(pf, ro, rd, z), z, True, False)
+        flips += int((idx.cpu().numpy().astype(np.int64) != ref["bin_indices"].numpy()).sum())
+        samples += idx.numel()
+        for k, got in (("fine_rgb_map", rgb), ("fine_depth_map", depth), ("alpha_map", acc)):
+            err[k] = max(err[k], float(np.abs(got.cpu().numpy() - ref[k].numpy().reshape(got.shape)).max()))
+    return {"rays": samples // N_IMPORTANCE, "fine_sample_indices": samples, "index_flips": flips,
+            "flip_rate": flips / max(samples, 1), "max_abs_err": err,
+            "note": "HIP coarse MLP -> HIP weights -> HIP indices vs oracle indices, same uniforms; stage-wise (same weights "
+                    "in) the indices are bit-exact (tests/test_gpu_parity.py), these flips come from last-bit differences "
+                    "of the coarse weights"}
 
 
 def train_cpu_baseline(seconds: float, rays_per_step: int = 256):
@@ -652,7 +687,7 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
                             "achieved": achieved, "peak": peak * world, "unit": "TFLOP/s", "frac": achieved / (peak * world),
                             "traffic": None}
     if cpu and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, None if bf16 else dev)
     return line
 
 
