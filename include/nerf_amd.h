@@ -261,8 +261,9 @@ int nrf_kilo_backward(const float* packed, const float* packed_t, int num_cells,
                       int64_t workspace_bytes, nrf_stream_t stream);
 
 /* Compact form of a set of cells' slices of the 12 batched (cells, ...) tensors: record u = the 12 per-cell slices
- * of cell cells[u] back to back (nrf_kilo_record_floats() = 6212 floats), `cells` a DEVICE list of distinct cell
- * indices (< num_cells; not range-checked on the device).  For the data-parallel gradient exchange: only cells some
+ * of cell cells[u] back to back (nrf_kilo_record_floats() = 6212 floats), `cells` a DEVICE list of cell indices.
+ * The indices MUST be distinct (scatter writes each listed cell once; duplicates race and are not detected); an index
+ * outside [0, num_cells) is skipped on the device (gather: its record is zeros; scatter: nothing is written).  For the data-parallel gradient exchange: only cells some
  * rank has samples in carry a gradient, so the ranks all-reduce n_cells records instead of all 25.4 M values.
  * The reference has no counterpart (DistributedDataParallel all-reduces every parameter, trainer.py:14-21). */
 int64_t nrf_kilo_record_floats(void);

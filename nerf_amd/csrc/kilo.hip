@@ -351,7 +351,7 @@ __global__ void scan_block_kernel(const int* __restrict__ in, int64_t n, int* __
 __global__ void scan_sums_kernel(int* __restrict__ sums, int nblocks, int64_t* __restrict__ total) {
     // single block, sequential over chunks of 1024 block sums
     __shared__ int s[kScanBlock];
-    __shared__ int carry;
+    __shared__ long long carry;   // the grand total may pass 2^31 (dense grids, fine steps): the caller must see it
     const int tid = threadIdx.x;
     if (tid == 0) carry = 0;
     __syncthreads();
@@ -366,7 +366,7 @@ __global__ void scan_sums_kernel(int* __restrict__ sums, int nblocks, int64_t* _
             s[tid] += a;
             __syncthreads();
         }
-        if (i < nblocks) sums[i] = carry + s[tid] - v;
+        if (i < nblocks) sums[i] = int(carry + s[tid] - v);   // offsets are int32: only meaningful while total < 2^31
         __syncthreads();
         if (tid == kScanBlock - 1) carry += s[tid];
         __syncthreads();

@@ -511,10 +511,15 @@ __global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ p
 // One workgroup per listed cell; every slice is a contiguous run on both sides (record = the 12 slices back to
 // back, kRecOff), so both directions are plain coalesced copies.
 template <bool GATHER>
-__global__ __launch_bounds__(256) void kilo_cells_copy_kernel(KiloSrc s, const int* __restrict__ cells,
+__global__ __launch_bounds__(256) void kilo_cells_copy_kernel(KiloSrc s, const int* __restrict__ cells, int num_cells,
                                                               float* __restrict__ records) {
     const int cell = cells[blockIdx.x];
     float* rec = records + int64_t(blockIdx.x) * kRecFloats;
+    if (cell < 0 || cell >= num_cells) {   // a stale / foreign index: touch no tensor; a gathered record reads as zeros
+        if (GATHER)
+            for (int i = threadIdx.x; i < kRecFloats; i += 256) rec[i] = 0.f;
+        return;
+    }
 #define COPY(K)                                                                                              \
     for (int i = threadIdx.x; i < REC_OFF(K + 1) - REC_OFF(K); i += 256) {                                   \
         float* g = const_cast<float*>(s.t[K]) + int64_t(cell) * (REC_OFF(K + 1) - REC_OFF(K)) + i;           \
@@ -540,9 +545,9 @@ static int cells_copy(bool gather, const float* const* tensors, const int32_t* c
     }
     nrf_launch_begin();
     if (gather)
-        kilo_cells_copy_kernel<true><<<dim3(unsigned(n_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, cells, records);
+        kilo_cells_copy_kernel<true><<<dim3(unsigned(n_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, cells, num_cells, records);
     else
-        kilo_cells_copy_kernel<false><<<dim3(unsigned(n_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, cells, records);
+        kilo_cells_copy_kernel<false><<<dim3(unsigned(n_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, cells, num_cells, records);
     return nrf_launch_status();
 }
 

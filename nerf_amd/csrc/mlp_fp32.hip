@@ -10,13 +10,16 @@
 //     (k = feature, column = point), the A operand is the weight matrix.  The accumulator
 //     layout of one layer (column = point on the lane, 16 rows in registers) is then exactly
 //     the B-operand layout of the next layer, so activations never leave the register file:
-//     no LDS, no barriers, no HBM round trips between the 10 GEMM layers.
+//     no LDS or HBM round trips of activations between the 10 GEMM layers.
 //   * One wavefront = 32 points x all 256 features: 128 accumulator registers in, 128 out
 //     (1 wave per SIMD, 512-register budget).
 //   * Weights are pre-permuted (nrf_pack_weights) into the order the wave consumes them, so
-//     the whole network is ONE linear 2.3 MiB stream of 1 KiB pieces per wavefront, read with
-//     global_load_dwordx4 through an 8-deep register ring (L2-resident: every wave streams
-//     the same bytes).  One float4 per lane feeds 4 MFMAs (256 matrix-core cycles).
+//     the whole network is ONE linear 2.3 MiB stream of 1 KiB steps.  The stream is fetched once
+//     per 4-wave workgroup (not per wave) by LDS-DMA (global_load_lds_dwordx4) into a 5 x 16 KiB
+//     LDS ring, 4 chunks ahead of use, one raw s_barrier per 16-step chunk (mlp_chain.h); each
+//     wave reads its A operands from the ring with ds_read_b128 one step ahead of the MFMAs.
+//     One float4 per lane feeds 4 MFMAs (256 matrix-core cycles).  L2-resident: every
+//     workgroup streams the same bytes.
 //   * PE (63 ch) and dir PE (27 ch) are computed in registers in the k-order the packed
 //     weights expect; alpha (256->1) and rgb (128->3) heads are VALU dot products.
 #include "mlp_chain.h"

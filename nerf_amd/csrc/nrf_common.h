@@ -71,7 +71,8 @@ constexpr int kStepsHidden = 8 * 8 * 4;  // 256 -> 256
 constexpr int kStepsSkip = 8 * 10 * 4;   // (64 PE + 256) -> 256
 constexpr int kStepsViews = 4 * 9 * 4;   // (256 + 32 dir PE) -> 128
 constexpr int kStreamSteps = kStepsL0 + 7 * kStepsHidden + kStepsSkip + kStepsViews;  // 2320
-constexpr int kPrefetch = 8;             // ring depth of the weight stream (steps)
+constexpr int kPrefetch = 8;             // steps of zero padding after each packed stream (the v1 register ring's depth;
+                                         // today only a pad the LDS-DMA prefetch may run into past the last layer)
 
 // stream offsets (in steps) of each MFMA layer: pts0..7, feature, views
 constexpr int kLayerStep[10] = {

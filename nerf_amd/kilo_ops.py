@@ -12,6 +12,18 @@ from .ops import _f32, _ptr, _stream
 from .weights import KILO_TENSORS
 
 
+MAX_POINTS = 1 << 28        # n_points limit of nrf_kilo_forward (int32 offsets, 2^28 x 16 B of raw)
+
+
+class TooManySamples(NrfError):
+    """The march of one call kept more samples than the packed path supports; render fewer rays per call."""
+
+    def __init__(self, total: int, n_rays: int):
+        super().__init__(f"kilo_march: {total} samples for {n_rays} rays exceed the {MAX_POINTS} a single call supports "
+                         "(dense occupancy grid / fine step): split the rays over several calls")
+        self.total = total
+
+
 def _grid_args(aabb, res):
     aabb = np.ascontiguousarray(np.asarray(aabb, dtype=np.float32).reshape(6))
     res = np.ascontiguousarray(np.asarray(res, dtype=np.int32).reshape(3))
@@ -220,6 +232,8 @@ def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: fl
                                          float(step), _ptr(counts), _ptr(offsets), _ptr(total), _ptr(ws), ws.numel(),
                                          _stream(rays_o)), "nrf_kilo_march_count")
         n = int(total.item())
+        if n > MAX_POINTS:
+            raise TooManySamples(n, R)
         pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
         ray_idx = torch.empty(n, dtype=torch.int32, device=dev)
         t_start = torch.empty(n, dtype=torch.float32, device=dev)

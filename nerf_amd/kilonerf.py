@@ -76,16 +76,18 @@ class KiloNetwork(nn.Module):
         self.register_buffer("aabb_min", torch.tensor(t.aabb["min"], dtype=torch.float32))
         self.register_buffer("aabb_max", torch.tensor(t.aabb["max"], dtype=torch.float32))
         self.register_buffer("grid_resolution", torch.tensor(t.grid_resolution, dtype=torch.long))
-        self._aabb = [float(v) for v in t.aabb["min"]] + [float(v) for v in t.aabb["max"]]
-        self._res = [int(v) for v in t.grid_resolution]
-        self.num_models = self._res[0] * self._res[1] * self._res[2]
+        res = [int(v) for v in t.grid_resolution]
+        self.num_models = res[0] * res[1] * res[2]
+        self._grid, self._grid_key = None, None
         self.white_bkgd = t.white_bkgd
         self.model = BatchedKiloNeRF(self.num_models)
         self._packed = None
         self._packed_key = None
 
     def grid(self):
-        return self._aabb, self._res
+        """(aabb, res) from the registered buffers the reference routes with (network.py:189-191, :322), which
+        load_state_dict / load_network overwrite; cached until a buffer changes (one host read per change)."""
+        return _grid_from_buffers(self, self)
 
     def packed(self) -> torch.Tensor:
         """Per-cell streaming layout, repacked only when a parameter changed (tensor versions)."""
@@ -106,7 +108,8 @@ class KiloNetwork(nn.Module):
         else:
             R, S = pts.shape[:2]
             di = torch.arange(R, device=pts.device, dtype=torch.int32).repeat_interleave(S)
-        raw = kilo_ops.kilo_forward(self.packed(), self.num_models, self._aabb, self._res, pts.reshape(-1, 3),
+        aabb, res = self.grid()
+        raw = kilo_ops.kilo_forward(self.packed(), self.num_models, aabb, res, pts.reshape(-1, 3),
                                     viewdirs, di).view(R, S, 4)
         return raw[..., :3], raw[..., 3:4]
 
@@ -115,6 +118,18 @@ class KiloNetwork(nn.Module):
         m = self.model
         return (torch.sum(m.view_linears_weights ** 2) + torch.sum(m.view_linears_biases ** 2) +
                 torch.sum(m.rgb_linear_weights ** 2) + torch.sum(m.rgb_linear_biases ** 2))
+
+
+def _grid_from_buffers(net, cache):
+    bufs = (net.aabb_min, net.aabb_max, net.grid_resolution)
+    key = tuple((b.data_ptr(), b._version) for b in bufs)
+    if cache._grid is None or cache._grid_key != key:
+        aabb = [float(v) for v in bufs[0].tolist()] + [float(v) for v in bufs[1].tolist()]
+        res = [int(v) for v in bufs[2].tolist()]
+        if res[0] * res[1] * res[2] != int(net.model.pts_linears_biases[0].shape[0]):
+            raise kilo_ops.NrfError(f"grid_resolution {res} does not match the {int(net.model.pts_linears_biases[0].shape[0])} cells of the parameter tensors")
+        cache._grid, cache._grid_key = (aabb, res), key
+    return cache._grid
 
 
 class KiloNetView:
@@ -127,7 +142,7 @@ class KiloNetView:
         self.net = net
         self._packed = None
         self._packed_key = None
-        self._grid = None
+        self._grid, self._grid_key = None, None
 
     def tensors(self):
         model = getattr(self.net, "model", None)
@@ -146,10 +161,7 @@ class KiloNetView:
     def grid(self):
         if hasattr(self.net, "grid"):
             return self.net.grid()
-        if self._grid is None:
-            aabb = [float(v) for v in self.net.aabb_min.tolist()] + [float(v) for v in self.net.aabb_max.tolist()]
-            self._grid = (aabb, [int(v) for v in self.net.grid_resolution.tolist()])
-        return self._grid
+        return _grid_from_buffers(self.net, self)
 
     def packed(self) -> torch.Tensor:
         if hasattr(self.net, "packed"):
@@ -191,12 +203,18 @@ class _KiloRenderFn(torch.autograd.Function):
         rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, renderer.ert, renderer.white_bkgd)
         ctx.renderer = renderer
         ctx.params = params
+        # `packed` is the network's cached buffer, rewritten in place by the next repack, and the backward packs the
+        # transposed operands from the live parameters: both are only the forward's weights while no parameter changes
+        ctx.versions = tuple(p._version for p in params)
         ctx.saved = (packed, pts, d, ray_idx, ts, te, offsets, counts, raw, ws)
         return rgb, depth, acc
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_acc):
         r = ctx.renderer
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise kilo_ops.NrfError("KiloRenderer: a parameter was modified between forward and backward (optimizer.step() "
+                                    "or another in-place update); call backward before updating the parameters")
         packed, pts, d, ray_idx, ts, te, offsets, counts, raw, ws = ctx.saved
         g_raw = kilo_ops.kilo_composite_backward(raw, ts, te, offsets, counts, r.ert, r.white_bkgd, g_rgb.contiguous(),
                                                  g_depth.contiguous(), g_acc.contiguous())
@@ -227,6 +245,10 @@ class KiloRenderer(nn.Module):
         self.occ_grid_resolution = [g * s.occ_factor for g in cfg.task_arg.grid_resolution]
         self.occ_grid = None
         self.last_num_samples = 0
+        # trainer.py:58-66 drives `renderer.estimator.update_every_n_steps(step, occ_eval_fn)` every iteration; the
+        # reference's estimator re-estimates the grid from the student's density while training (nerf_amd/estimator.py)
+        from .estimator import GridEstimator
+        self.estimator = GridEstimator(self, self.view.grid()[0], self.occ_grid_resolution)
         if occ_grid is not None:
             self.set_occ_grid(occ_grid)
         elif ref_cfg is not None:
@@ -293,6 +315,21 @@ class KiloRenderer(nn.Module):
         return {"rgb_map": rgb.view(B, R, 3), "depth_map": depth.view(B, R, 1), "alpha_map": acc.view(B, R, 1)}
 
     def _render(self, o, d):
+        """One march / forward / composite when the samples fit a call, else the rays in halves (dense grids)."""
+        try:
+            self.last_num_samples = 0
+            return self._render_once(o, d)
+        except kilo_ops.TooManySamples:
+            h = o.shape[0] // 2
+            if h == 0:
+                raise
+            a = self._render(o[:h].contiguous(), d[:h].contiguous())
+            n = self.last_num_samples
+            b = self._render(o[h:].contiguous(), d[h:].contiguous())
+            self.last_num_samples += n
+            return tuple(torch.cat([x, y]) for x, y in zip(a, b))
+
+    def _render_once(self, o, d):
         aabb, res = self.view.grid()
         occ = self.occ_grid
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, occ, aabb, self.near, self.far, self.step)

@@ -54,12 +54,18 @@ class _RenderTrainFn(torch.autograd.Function):
         raw_f, acts_f, masks_f = ops.mlp_forward_rays_train(pf, rays_o, rays_d, z_f)
         f_rgb, f_depth, _, f_acc = ops.composite(raw_f, z_f, white, False)
         ctx.renderer, ctx.white = renderer, white
+        # pc / pf / pc_t / pf_t are the renderer's cached packed buffers, rewritten in place by the next repack: they
+        # are the forward's weights only while no parameter changes before backward
+        ctx.params, ctx.versions = params, tuple(p._version for p in params)
         ctx.saved = (pc, pc_t, raw_c, zc, acts_c, masks_c, pf, pf_t, raw_f, z_f, acts_f, masks_f)
         renderer.coarse_samples, renderer.fine_samples = zc, z_f
         return c_rgb, c_depth, f_rgb, f_depth, f_acc
 
     @staticmethod
     def backward(ctx, g_c_rgb, g_c_depth, g_f_rgb, g_f_depth, g_f_acc):
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise NrfError("Renderer: a parameter was modified between forward and backward (optimizer.step() or another "
+                           "in-place update); call backward before updating the parameters")
         pc, pc_t, raw_c, zc, acts_c, masks_c, pf, pf_t, raw_f, z_f, acts_f, masks_f = ctx.saved
         r = ctx.renderer
         g_raw_c = ops.composite_backward(raw_c, zc, ctx.white, g_c_rgb, g_c_depth, None)
@@ -125,6 +131,15 @@ class Renderer(nn.Module):
         self.occupancy_forward = bool(getattr(ta, "occupancy_forward", False))
         self.render_step_size, self.early_stop_eps = 1e-3, 1e-4   # nerfacc's defaults, which the reference does not override (:90-96)
         self.last_num_samples = 0
+        # what trainer.py:58-66 calls every iteration (the reference's nerfacc estimator, :38-47); it re-estimates
+        # `occ_grid` only while the occupancy path is the one in use -- the classic path does not sample through it
+        from .estimator import GridEstimator
+        self.estimator = GridEstimator(self, self.scene_aabb, self.occ_grid_resolution, active=lambda: self.occupancy_forward)
+
+    def set_occ_grid(self, occ_grid: torch.Tensor):
+        if list(occ_grid.shape) != list(self.occ_grid_resolution):
+            raise ValueError(f"occupancy grid {tuple(occ_grid.shape)} != {self.occ_grid_resolution}")
+        self.occ_grid = occ_grid.to(torch.uint8).contiguous()
 
     # ---- occupancy-grid path (volume_renderer.py:50-139 + 156-197; sampling / compositing rule: DESIGN.md section 7) ----
     @torch.no_grad()
@@ -134,8 +149,8 @@ class Renderer(nn.Module):
         from . import kilo_ops
         dev = torch.device(device) if device is not None else next(self.net.parameters()).device
         packed = self._packed_model("model", dev)
-        self.occ_grid = kilo_ops.occ_bake(packed, self.scene_aabb, self.occ_grid_resolution, occ_thre, chunk_cells,
-                                          vertices=True).to(torch.uint8)
+        self.set_occ_grid(kilo_ops.occ_bake(packed, self.scene_aabb, self.occ_grid_resolution, occ_thre, chunk_cells,
+                                            vertices=True))
         return self.occ_grid
 
     @torch.no_grad()
@@ -157,16 +172,31 @@ class Renderer(nn.Module):
             self.build_occ_grid(device=dev)                       # the reference bakes it in __init__ (:46-47)
         if self.occ_grid.device != dev:
             self.occ_grid = self.occ_grid.to(dev)
-        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, self.occ_grid, self.scene_aabb, self.near, self.far,
-                                                                    self.render_step_size)
-        self.last_num_samples = n = int(pts.shape[0])
-        if n:
-            bf16 = self.mlp_dtype == "bf16"
-            fwd = ops.mlp_forward_points_bf16 if bf16 else ops.mlp_forward_points
-            raw = fwd(self._packed_model("model", dev, bf16), pts, d.index_select(0, ray_idx.long()))
-        else:
-            raw = torch.empty((0, 4), dtype=torch.float32, device=dev)
-        rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.early_stop_eps, self.white_bkgd > 0)
+        self.last_num_samples = 0
+
+        def rays(o, d):
+            """One march / MLP / composite when the samples fit a call, else the rays in halves (an 800x800 frame at step
+            1e-3 through a mostly occupied grid is ~2e9 samples)."""
+            try:
+                pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, self.occ_grid, self.scene_aabb, self.near,
+                                                                            self.far, self.render_step_size)
+            except kilo_ops.TooManySamples:
+                h = o.shape[0] // 2
+                if h == 0:
+                    raise
+                a, b = rays(o[:h].contiguous(), d[:h].contiguous()), rays(o[h:].contiguous(), d[h:].contiguous())
+                return tuple(torch.cat([x, y]) for x, y in zip(a, b))
+            n = int(pts.shape[0])
+            self.last_num_samples += n
+            if n:
+                bf16 = self.mlp_dtype == "bf16"
+                fwd = ops.mlp_forward_points_bf16 if bf16 else ops.mlp_forward_points
+                raw = fwd(self._packed_model("model", dev, bf16), pts, d.index_select(0, ray_idx.long()))
+            else:
+                raw = torch.empty((0, 4), dtype=torch.float32, device=dev)
+            return kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.early_stop_eps, self.white_bkgd > 0)
+
+        rgb, depth, acc = rays(o, d)
         rgb, depth, acc = rgb.view(B, R, 3), depth.view(B, R, 1), acc.view(B, R, 1)
         return {"fine_rgb_map": rgb, "fine_depth_map": depth, "alpha_map": acc,
                 "rgb_map": rgb, "depth_map": depth, "acc_map": acc}

@@ -42,6 +42,16 @@ def test_route_bit_exact(golden, dev):
     assert np.array_equal(cell.astype(np.int64), fx["flat"])
 
 
+def test_route_non_finite_vs_reference_fixture(golden, dev):
+    """+-inf: bit-exact with the reference (tests/golden/kilo_route_nonfinite.npz, made by the real _get_index);
+    NaN: the reference yields INT64_MIN and then fails to index, the kernel routes to cell 0 (documented difference)."""
+    from nerf_amd import kilo_ops
+    fx = golden("kilo_route_nonfinite")
+    cell = kilo_ops.kilo_route(_t(fx["pts"], dev), AABB, RES).cpu().numpy().astype(np.int64)
+    i3 = np.where(np.isnan(fx["pts"]), 0, fx["index3"])
+    assert np.array_equal(cell, i3[:, 0] * 256 + i3[:, 1] * 16 + i3[:, 2])
+
+
 def test_route_nan_inf_and_empty(dev):
     from nerf_amd import kilo_ops
     from oracle import kilo_oracle as K

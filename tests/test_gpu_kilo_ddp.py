@@ -3,6 +3,8 @@ nerf_amd.parallel.allreduce_cell_gradients) against plain torch indexing, and --
 one GPU of the test box -- against the dense all-reduce of the flat gradient buffer (DDP's semantics,
 src/train/trainers/trainer.py:14-21)."""
 import os
+import queue
+import time
 import sys
 
 import numpy as np
@@ -97,9 +99,23 @@ def test_two_ranks_compact_exchange_equals_dense_allreduce(dev):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=150) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
+    res, deadline = [], time.time() + 150
+    try:
+        while len(res) < len(procs):
+            try:
+                res.append(q.get(timeout=1.0))
+            except queue.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f"a worker died with exit code {dead} before reporting"
+                assert time.time() < deadline, "workers did not report within 150 s"
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:              # a failed or hung run leaves no worker behind (exact handles, no patterns)
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    res.sort()
     for rank, ok_grad, ok_param, touched, dg, dp in res:
         assert ok_grad and ok_param, (rank, dg, dp)
         assert 0 < touched < 4096

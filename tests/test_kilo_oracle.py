@@ -17,6 +17,19 @@ def test_route_matches_reference_bit_exact(golden):
     assert flat.min() == 0 and flat.max() == 4095
 
 
+def test_route_non_finite_points_vs_reference(golden):
+    """+-inf coordinates have a defined answer in the reference (clamped to the first / last cell, network.py:329-331)
+    and the oracle reproduces it; NaN does not: the reference's `.long()` of NaN is INT64_MIN (recorded in the fixture)
+    and its next line indexes with it and raises.  The oracle -- and kilo_route_kernel -- send a NaN coordinate to
+    cell 0 instead: a documented difference, not a pinned one."""
+    fx = golden("kilo_route_nonfinite")
+    idx3, _ = K.route(fx["pts"], AABB_MIN, AABB_MAX, RES)
+    finite = ~np.isnan(fx["pts"])
+    assert np.array_equal(idx3[finite], fx["index3"][finite])
+    assert (fx["index3"][~finite] == np.iinfo(np.int64).min).all()         # what the reference does with NaN
+    assert (idx3[~finite] == 0).all()
+
+
 def _sd(fx):
     return make_kilo_state_dict_arrays(int(fx["weight_seed"]), 4096, float(fx["density_gain"]), float(fx["density_bias"]))
 

@@ -95,3 +95,16 @@ for name, _, _ in KILO_TENSORS:
     out["abssum." + name] = np.float64(gr.double().abs().sum())
 np.savez_compressed(os.path.join(OUT, "kilo_network_grad.npz"), **out)
 print("kilo_network_grad cells", pick, out["cell_counts"], {k: float(v) for k, v in out.items() if k.startswith("abssum.")})
+
+# ---- non-finite coordinates through the reference's _get_index (network.py:314-334) ----
+# +-inf survive the clamp (:329-331: clamp(min=0) then min(res - 1)); NaN passes both clamps unchanged and `.long()` of
+# NaN is whatever the CPU's cvttss2si returns (INT64_MIN on x86), which the reference then uses as an index and fails.
+# The fixture records exactly what the reference returned here, so the HIP kernel's choices are pinned where the
+# reference has a defined answer (+-inf) and documented where it has none (NaN -> cell 0 in kilo_route_kernel).
+inf = float("inf")
+nf = torch.tensor([[inf, 0.0, 0.0], [-inf, 0.0, 0.0], [0.3, inf, -inf], [inf, inf, inf], [-inf, -inf, -inf],
+                   [0.0, -0.2, inf], [float("nan"), 0.0, 0.0], [0.5, float("nan"), float("nan")]], dtype=torch.float32)
+with torch.no_grad():
+    nf3 = net._get_index(nf)
+np.savez_compressed(os.path.join(OUT, "kilo_route_nonfinite.npz"), pts=nf.numpy(), index3=nf3.numpy())
+print("kilo_route_nonfinite", nf3.tolist())
