@@ -8,14 +8,25 @@
 //     accumulator initialisers; point construction, sin/cos, the alpha / rgb heads (fp32 weights, VALU) are fp32.
 //
 // Shape (what differs from the fp32 kernel): one MFMA now covers 16 k for 32 cycles (16x the fp32 rate), so the
-// weight stream, not the matrix pipe, is the thing to feed: a wavefront owns 64 points (two 32-point accumulator
-// sets that share every weight operand: one ds_read_b128 per 2 MFMAs), the LDS ring moves 32-KiB chunks (one
-// barrier per 2048 matrix cycles) and its LDS-DMA refills are spread one piece every 4 steps.  Activations live in
-// registers as bf16 B fragments (v_cvt_pk_bf16_f32 of accumulator registers 8s..8s+7 = the fragment of k-step s,
-// cdna_hip_programming.md section 3): a finished 32-row output block is activated and packed while the next
-// block accumulates, so only two fp32 accumulator blocks per point set are ever live and the layer's input and
-// output (128 registers each) ping-pong between two register arrays.
+// weight stream and everything that is not an MFMA, not the matrix pipe, are the things to manage.  Activations live
+// in registers as bf16 B fragments (v_cvt_pk_bf16_f32 of accumulator registers 8s..8s+7 = the fragment of k-step s,
+// cdna_hip_programming.md section 3): a finished 32-row output block is activated and packed while the next block
+// accumulates, so only two fp32 accumulator blocks per point set are ever live and the layer's input and output
+// ping-pong between two register arrays.  The LDS ring moves 32-KiB chunks (one barrier per 2048 matrix cycles per
+// SIMD) and its LDS-DMA refills are spread over the chunk's steps.
+//
+// Two tilings of the same chain (template NSETS; every workgroup covers 256 points per pass of the weight stream):
+//   NSETS = 1 (default): EIGHT waves per workgroup, two per SIMD, each owning ONE 32-point set.  A wave's registers
+//     (two 64-register activation arrays, two accumulator blocks, encodings, the operand look-ahead) fit the 256
+//     architectural VGPRs a wave gets at two per SIMD, so nothing ever moves between VGPRs and AGPRs, and a wave's
+//     activation epilogues, LDS waits, encoding and heads run under its SIMD partner's MFMAs.
+//   NSETS = 2 (round 1, NRF_BF16_SETS=2): four waves, one per SIMD, each owning two 32-point sets that share every
+//     weight operand (one ds_read_b128 per 2 MFMAs).  It needs 486 registers, so half of the activations live in AGPRs
+//     and every layer pays VGPR<->AGPR copies plus un-hidden epilogues: the phase stamps of tools/ubench/bf16_phase.hip
+//     show 52 % of a tile's cycles in MFMAs.
 #include "mlp_chain.h"
+
+#include <cstdlib>
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -88,21 +99,29 @@ __global__ void bpack_layer_kernel(BPackLayer p) {
 
 // ---- LDS ring of the bf16 stream --------------------------------------------------------------
 struct BRing {
-    const char* gnext;   // per lane: this lane's 16 B of piece 8w of the next chunk to prefetch
+    const char* gnext;   // per lane: this lane's 16 B of piece PW*w of the next chunk to prefetch
     const char* gbegin;
     const char* gend;
-    unsigned lds_base;   // LDS byte address of smem + wave * 8 KiB (this wave fills pieces 8w..8w+7)
+    unsigned lds_base;   // LDS byte address of smem + wave * PW KiB (this wave fills pieces PW*w .. PW*w+PW-1)
     char* smem;
     int pf_slot, rd_slot;
     const u32x4* rd;     // this lane's 16 B of step 0 of the chunk being read
     u32x4 wq[4];         // weights of steps s .. s+2 (slot = step & 3), read kLook steps ahead of their MFMAs
+#ifdef BF_STAMP
+    int stamp_base;      // >= 0: bf_layer stamps the start of every output block at g_bf_stamps[.. + stamp_base + ob]
+    int stamp_wave;
+#endif
 };
 
 __device__ __forceinline__ void br_prefetch_piece(const BRing& st, int j) {
 #ifdef BF_ABL_NODMA  // timing-only ablation builds (tools/debug/bf16_ablate.py): results are wrong
     return;
 #endif
+#ifdef BF_STAMP  // the stamps' lane-0 stores make the compiler lose the uniformity of the slot index
+    glds16(st.gnext + j * 1024, __builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kBChunkBytes + j * 1024));
+#else
     glds16(st.gnext + j * 1024, st.lds_base + unsigned(st.pf_slot) * kBChunkBytes + j * 1024);
+#endif
 }
 __device__ __forceinline__ void br_prefetch_advance(BRing& st) {
     const char* nx = st.gnext + kBChunkBytes;
@@ -110,38 +129,56 @@ __device__ __forceinline__ void br_prefetch_advance(BRing& st) {
     asm volatile("" : "+v"(st.gnext));  // keep it a run-time value (see ws_prefetch_advance)
     st.pf_slot = st.pf_slot + 1 == kBRing ? 0 : st.pf_slot + 1;
 }
-// Next chunk readable: it was issued two chunk-times ago; the two batches of 8 pieces issued since may stay in
-// flight.  The barrier also says every wave is done reading the current chunk (its slot is refilled next).
+// Next chunk readable: it was issued two chunk-times ago; the two batches of PW pieces (PW = 32 / waves: this wave's
+// share of a chunk) issued since may stay in flight.  The barrier also says every wave is done reading the current
+// chunk (its slot is refilled next).
+template <int PW>
 __device__ __forceinline__ void br_acquire(BRing& st, int lane) {
 #ifndef BF_ABL_NOBARRIER
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(2 * PW) : "memory");
     __builtin_amdgcn_s_barrier();
 #endif
     st.rd_slot = st.rd_slot + 1 == kBRing ? 0 : st.rd_slot + 1;
     st.rd = reinterpret_cast<const u32x4*>(st.smem + st.rd_slot * kBChunkBytes) + lane;
 }
-// Chunks 0..2 are fetched up front; while chunk c is consumed the wave issues its 8 pieces of chunk c+3 into the
+// Chunks 0..2 are fetched up front; while chunk c is consumed the wave issues its PW pieces of chunk c+3 into the
 // slot chunk c-1 just left.
+template <int PW>
 __device__ __forceinline__ void br_start(BRing& st, const char* stream_base, char* smem, int wave, int lane) {
-    st.gbegin = stream_base + wave * 8192 + lane * 16;
+    st.gbegin = stream_base + wave * (PW * 1024) + lane * 16;
     st.gend = st.gbegin + size_t(kBChunks) * kBChunkBytes;
     st.gnext = st.gbegin;
     st.smem = smem;
-    st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * 8192u);
+    st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * unsigned(PW * 1024));
     st.pf_slot = 0;
 #pragma unroll
     for (int i = 0; i < kBRing - 1; ++i) {
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) br_prefetch_piece(st, jj);
+        for (int jj = 0; jj < PW; ++jj) br_prefetch_piece(st, jj);
         br_prefetch_advance(st);
     }
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
     __builtin_amdgcn_s_barrier();
     st.rd_slot = 0;
     st.rd = reinterpret_cast<const u32x4*>(smem) + lane;
 #pragma unroll
     for (int i = 0; i < kLook; ++i) st.wq[i] = st.rd[i * 64];
 }
+
+// Diagnostic builds only (tools/ubench/bf16_phase.hip, -DBF_STAMP): s_memtime at phase boundaries of one tile per wave,
+// written to a buffer of their own that nothing else reads.  In the shipped kernel the macro is empty.
+#ifdef BF_STAMP
+__device__ unsigned long long g_bf_stamps[256 * 8 * 128];
+#define BF_STAMP_AT(i)                                                                                       \
+    do {                                                                                                     \
+        if (stamp_tile) {                                                                                    \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                      \
+            if (lane == 0) g_bf_stamps[st.stamp_wave * 128 + (i)] = t_;                             \
+        }                                                                                                    \
+    } while (0)
+#else
+#define BF_STAMP_AT(i) do {} while (0)
+#endif
 
 #define NRF_MFMA_BF16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
@@ -162,96 +199,162 @@ __device__ __forceinline__ void act_pack(const f32x16& y, int lim, u32x4 out[2])
 }
 constexpr int kActRelu = 0, kActNone = int(0x80000000u);
 
-struct EpiPack {  // hidden layers: pack + activate block ob of both sets into the next layer's input
+// Block epilogues come in SLICES.  A finished 32-row block needs 3 VALU instructions per packed output register
+// (two v_max_i32 on the fp32 bits, one v_cvt_pk_bf16_f32), 48 or 96 per block; issued as one lump they stop the wave's
+// in-order MFMA issue for hundreds of cycles (phase stamps, tools/ubench/bf16_phase.hip: 1340-1550 cycles per block of
+// 1024 MFMA cycles).  Two or three VALU instructions per MFMA gap hide completely (tools/ubench/mfma_valu_overlap.hip:
+// up to 6 per gap are free), so bf_layer hands every step of block ob its share of block ob-1's epilogue, and the LAST
+// block's epilogue of a layer travels into the first block of the next layer (`pending`), where its output -- input
+// block 7 -- is not read before step 14.
+template <int NSETS>
+struct EpiPack {  // hidden layers: activate + pack block ob of every set into the next layer's input
+    static constexpr int Q = 8 * NSETS;   // slices per block: one packed output register each
     u32x4 (*Xout)[8][2];
-    int lim;
-    __device__ __forceinline__ void operator()(int ob, const f32x16& ya, const f32x16& yb) {
-        act_pack(ya, lim, Xout[0][ob]);
-        act_pack(yb, lim, Xout[1][ob]);
+    int lim;                              // kActRelu / kActNone: see act_pack
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void slice(int ob, const f32x16 (&y)[NSETS], int q) {
+        const int set = q / 8, s = (q % 8) / 4, i = q % 4;
+        const int b0 = __float_as_int(y[set][8 * s + 2 * i]), b1 = __float_as_int(y[set][8 * s + 2 * i + 1]);
+        Xout[set][ob][s][i] = pack_bf16(__int_as_float(b0 > lim ? b0 : lim), __int_as_float(b1 > lim ? b1 : lim));
     }
 };
+template <int NSETS>
 struct EpiRgb {  // views layer: relu + the rgb head's partial dot products (fp32 weights on the VALU)
+    static constexpr int Q = 16 * NSETS;  // one accumulator register (a row pair of the block) per slice
     const float* rw;  // cst + rgb weights + h * 16
-    float acc[2][3];
-    __device__ __forceinline__ void operator()(int ob, const f32x16& ya, const f32x16& yb) {
-        const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + ob * 32);
-        const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + ob * 32);
-        const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + ob * 32);
-        const f32x16 ha = relu16(ya), hb = relu16(yb);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            acc[0][0] = fmaf(w0[t], ha[t], acc[0][0]), acc[0][1] = fmaf(w1[t], ha[t], acc[0][1]), acc[0][2] = fmaf(w2[t], ha[t], acc[0][2]);
-            acc[1][0] = fmaf(w0[t], hb[t], acc[1][0]), acc[1][1] = fmaf(w1[t], hb[t], acc[1][1]), acc[1][2] = fmaf(w2[t], hb[t], acc[1][2]);
-        }
+    float acc[NSETS][3];
+    f32x16 w0, w1, w2;
+    __device__ __forceinline__ void begin(int ob) {
+        w0 = *reinterpret_cast<const f32x16*>(rw + ob * 32);
+        w1 = *reinterpret_cast<const f32x16*>(rw + 128 + ob * 32);
+        w2 = *reinterpret_cast<const f32x16*>(rw + 256 + ob * 32);
+    }
+    __device__ __forceinline__ void slice(int, const f32x16 (&y)[NSETS], int q) {
+        const int set = q / 16, t = q % 16;
+        const int b = __float_as_int(y[set][t]);
+        const float hv = __int_as_float(b > 0 ? b : 0);
+        acc[set][0] = fmaf(w0[t], hv, acc[set][0]);
+        acc[set][1] = fmaf(w1[t], hv, acc[set][1]);
+        acc[set][2] = fmaf(w2[t], hv, acc[set][2]);
     }
 };
 
-// One GEMM layer for this wave's two 32-point sets: block ob of the output = bias + sum_k W . [pre, Xin, post].
-// The epilogue of block ob-1 (activation + pack, or the rgb head) runs early in block ob's k loop, when the MFMAs
-// that produced it have long drained.  NS steps are consumed; the layer occupies NSPAD steps of the stream.
-template <int NOB, int NPRE, int NHID, int NPOST, int NSPAD, class Epi>
+// One GEMM layer for this wave's NSETS 32-point sets: block ob of the output = bias + sum_k W . [pre, Xin, post].
+// `acc` ([ob & 1][set]) is owned by the caller so that the last block's accumulators survive the call: its epilogue is
+// the NEXT layer's `pend` (PEND: the previous layer left one; the views layer, last of the tile, is followed by an
+// explicit bf_finish).  NS steps are consumed; the layer occupies NSPAD steps of the stream.
+template <int NSETS, int NOB, int NPRE, int NHID, int NPOST, int NSPAD, bool PEND, class Epi>
 __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_h, const u32x4 (*pre)[2][2],
-                                         const u32x4 (*Xin)[8][2], const u32x4 (*post)[2], Epi& epi) {
+                                         const u32x4 (*Xin)[8][2], const u32x4 (*post)[2], Epi& epi,
+                                         f32x16 (&acc)[2][NSETS], EpiPack<NSETS>& pend) {
     constexpr int NKB = NPRE + NHID + NPOST;
-    constexpr int NS = NOB * NKB * 2;
+    constexpr int SB = NKB * 2;                    // steps per output block
+    constexpr int NS = NOB * SB;
+    constexpr int PW = 4 * NSETS;                  // LDS-DMA pieces per wave per chunk: 32 / (8 / NSETS waves)
+    constexpr int GAP = kBChunkSteps / PW;         // one piece every GAP steps
+    constexpr int S0 = SB >= 8 ? 2 : 1;            // first step of a block that carries epilogue slices (the producing
+                                                   // MFMAs have drained by then)
+    constexpr int PE = (NPRE + 7) * 2 - 1;         // the pending epilogue writes input block 7, first read at step
+                                                   // (NPRE + 7) * 2: its last slice comes two steps earlier
+    static_assert(NOB % 2 == 0, "the last block must leave its accumulators in acc[1], the next layer starts in acc[0]");
+    static_assert(!PEND || (NHID == 8 && PE > S0), "a pending epilogue needs a layer that reads 8 input blocks");
     static_assert(NSPAD % kBChunkSteps == 0 && NSPAD >= NS && NSPAD - NS < kBChunkSteps, "layer padding");
     static_assert(NS % 4 == 0 && (NS % kBChunkSteps == 0 || (NS % kBChunkSteps) % 4 == 0) && (NS % kBChunkSteps == 0 || NS % kBChunkSteps > kLook),
                   "register ring phase / tail length");
-    f32x16 acc[2][2];  // [ob & 1][set]
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
+#ifdef BF_STAMP
+        if (st.stamp_base >= 0) {
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+            if (lane == 0) g_bf_stamps[st.stamp_wave * 128 + st.stamp_base + ob] = t_;
+        }
+#endif
         const f32x16 bias = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);  // srcC of the block's first MFMAs
+        if (ob > 0) epi.begin(ob - 1);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (ob > 0 && kb == 1) epi(ob - 1, acc[(ob - 1) & 1][0], acc[(ob - 1) & 1][1]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 // Step s uses the weights in register slot s & 3 and issues the LDS read of step s + kLook (one
-                // ds_read_b128 in flight across ~3 steps = 6 MFMAs, so its latency never surfaces).  The hand-over to
+                // ds_read_b128 in flight across ~3 steps, so its latency never surfaces).  The hand-over to
                 // the next ring chunk comes kLook steps before the chunk's end, right after the read of its last step
                 // was issued: by then every wave has ISSUED all its reads of the chunk (and br_acquire drains them
                 // before the barrier), so the chunk's slot may be refilled from the next chunk's step 0 on.
-                const int s = (ob * NKB + kb) * 2 + s2;
+                const int sb = kb * 2 + s2;                                             // step inside the block
+                const int s = ob * SB + sb;
                 const int cs = s % kBChunkSteps;                                        // position inside the ring chunk
                 const int cend = (s - cs + kBChunkSteps - 1) < NS - 1 ? (s - cs + kBChunkSteps - 1) : NS - 1;  // chunk's last step
                 const bool tail = cend - (s - cs) + 1 < kBChunkSteps;                   // padded (short) last chunk of the layer
                 const u32x4 w = st.wq[s & 3];
                 const int r = s + kLook;
                 if (r <= cend) st.wq[r & 3] = st.rd[(cs + kLook) * 64];
-                if (cs % 4 == 0) {                                                      // this chunk-time's refill pieces
+                const bool slot = cs % GAP == 0;                                        // this chunk-time's refill pieces
+                const bool flush = tail && s == cend - kLook;                           // short chunk: issue what its steps never reach
+                if (slot || flush) {
                     __builtin_amdgcn_sched_barrier(0);
-                    br_prefetch_piece(st, cs / 4);
-                    if (s == cend - kLook && tail) {
+                    if (slot) br_prefetch_piece(st, cs / GAP);
+                    if (flush) {
 #pragma unroll
-                        for (int jj = cs / 4 + 1; jj < 8; ++jj) br_prefetch_piece(st, jj);
+                        for (int jj = cs / GAP + 1; jj < PW; ++jj) br_prefetch_piece(st, jj);
                     }
-                    if (cs / 4 == 7 || (s == cend - kLook && tail)) br_prefetch_advance(st);
+                    if ((slot && cs / GAP == PW - 1) || flush) br_prefetch_advance(st);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (s == cend - kLook) br_acquire(st, lane);
+                if (s == cend - kLook) br_acquire<PW>(st, lane);
                 if (r > cend) st.wq[r & 3] = st.rd[(r - cend - 1) * 64];
-                const u32x4 xa = kb < NPRE ? pre[0][kb][s2] : (kb < NPRE + NHID ? Xin[0][kb - NPRE][s2] : post[0][s2]);
-                const u32x4 xb = kb < NPRE ? pre[1][kb][s2] : (kb < NPRE + NHID ? Xin[1][kb - NPRE][s2] : post[1][s2]);
+                // this step's share of the previous block's epilogue (own layer: block ob-1; block 0: the pending one)
+                if (sb >= S0) {
+                    if (ob > 0) {
+                        constexpr int Q = Epi::Q;
+#pragma unroll
+                        for (int q = Q * (sb - S0) / (SB - S0); q < Q * (sb - S0 + 1) / (SB - S0); ++q)
+                            epi.slice(ob - 1, acc[(ob - 1) & 1], q);
+                    } else if (PEND && sb < PE) {
+                        constexpr int Q = EpiPack<NSETS>::Q;
+#pragma unroll
+                        for (int q = Q * (sb - S0) / (PE - S0); q < Q * (sb - S0 + 1) / (PE - S0); ++q)
+                            pend.slice(7, acc[1], q);
+                    }
+                }
                 const bool first = kb == 0 && s2 == 0;
-                acc[ob & 1][0] = NRF_MFMA_BF16(w, xa, first ? bias : acc[ob & 1][0]);
-                acc[ob & 1][1] = NRF_MFMA_BF16(w, xb, first ? bias : acc[ob & 1][1]);
+#pragma unroll
+                for (int set = 0; set < NSETS; ++set) {
+                    const u32x4 x = kb < NPRE ? pre[set][kb][s2] : (kb < NPRE + NHID ? Xin[set][kb - NPRE][s2] : post[set][s2]);
+                    acc[ob & 1][set] = NRF_MFMA_BF16(w, x, first ? bias : acc[ob & 1][set]);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the slices where they are: one step = one scheduling region
             }
         }
     }
-    epi(NOB - 1, acc[(NOB - 1) & 1][0], acc[(NOB - 1) & 1][1]);
+#ifdef BF_STAMP
+    if (st.stamp_base >= 0) {
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+        if (lane == 0) g_bf_stamps[st.stamp_wave * 128 + st.stamp_base + 8] = t_;
+        if (lane == 0) g_bf_stamps[st.stamp_wave * 128 + st.stamp_base + 9] = t_;
+    }
+#endif
+}
+// the epilogue of a layer's last block when no further layer carries it (end of the tile)
+template <int NSETS, int NOB, class Epi>
+__device__ __forceinline__ void bf_finish(Epi& epi, f32x16 (&acc)[2][NSETS]) {
+    epi.begin(NOB - 1);
+#pragma unroll
+    for (int q = 0; q < Epi::Q; ++q) epi.slice(NOB - 1, acc[(NOB - 1) & 1], q);
 }
 
 __device__ __forceinline__ float bf_lo(unsigned r) { return __uint_as_float(r << 16); }
 __device__ __forceinline__ float bf_hi(unsigned r) { return __uint_as_float(r & 0xffff0000u); }
 
-// Persistent, one 4-wave workgroup per CU, one wave per SIMD; a wave's tile = 64 consecutive samples of one ray, or
-// (POINTS: Network.forward on a flat batch, network.py:184-186) 64 consecutive points with their own directions,
-// used as given; then rays_o = pts (n, 3), rays_d = dirs (n, 3), n_points bounds the last tile.
-template <bool POINTS>
-__global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict__ packed, const float* __restrict__ rays_o,
-                                                          const float* __restrict__ rays_d, const float* __restrict__ zbuf,
-                                                          int64_t z_stride, int tiles_per_ray, int64_t n_tiles,
-                                                          int64_t n_groups, int64_t n_points, float4* __restrict__ raw) {
+// Persistent, one workgroup of 8 / NSETS waves per CU (NSETS = 1: two waves per SIMD; NSETS = 2: one); a wave's tile =
+// 32 * NSETS consecutive samples of one ray, or (POINTS: Network.forward on a flat batch, network.py:184-186) that many
+// consecutive points with their own directions, used as given; then rays_o = pts (n, 3), rays_d = dirs (n, 3),
+// n_points bounds the last tile.
+template <bool POINTS, int NSETS>
+__global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const char* __restrict__ packed, const float* __restrict__ rays_o,
+                                                                         const float* __restrict__ rays_d, const float* __restrict__ zbuf,
+                                                                         int64_t z_stride, int tiles_per_ray, int64_t n_tiles,
+                                                                         int64_t n_groups, int64_t n_points, float4* __restrict__ raw) {
+    constexpr int WAVES = 8 / NSETS, PW = 4 * NSETS, TP = 32 * NSETS;   // waves per workgroup, DMA pieces per wave, points per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -259,24 +362,30 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
     {
         const float4* src = reinterpret_cast<const float4*>(packed + kBSmallFloatOff * 4);
         float4* dst = reinterpret_cast<float4*>(smem + kBLdsConstOff);
-        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 64 * WAVES) dst[i] = src[i];
     }
     __syncthreads();
     const float* cst = reinterpret_cast<const float*>(smem + kBLdsConstOff);
     const float* bias_h = cst + h * 16;
 
     BRing st;
-    br_start(st, packed, smem, wave, lane);
+    br_start<PW>(st, packed, smem, wave, lane);
 
     for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
-        int64_t tile = tg * 4 + wave;
+        int64_t tile = tg * WAVES + wave;
         const bool valid = tile < n_tiles;
         if (!valid) tile = n_tiles - 1;
-        u32x4 pe[2][2][2], dpe[2][2];
+#ifdef BF_STAMP
+        const bool stamp_tile = tg == int64_t(blockIdx.x) + 4 * int64_t(gridDim.x);
+        st.stamp_wave = blockIdx.x * WAVES + wave;
+        st.stamp_base = -1;
+#endif
+        BF_STAMP_AT(0);
+        u32x4 pe[NSETS][2][2], dpe[NSETS][2];
         if constexpr (POINTS) {
 #pragma unroll
-            for (int set = 0; set < 2; ++set) {
-                int64_t pt = tile * 64 + 32 * set + j;
+            for (int set = 0; set < NSETS; ++set) {
+                int64_t pt = tile * TP + 32 * set + j;
                 pt = pt < n_points ? pt : n_points - 1;   // tail lanes repeat the last point (stores are masked)
                 const float px = rays_o[pt * 3], py = rays_o[pt * 3 + 1], pz = rays_o[pt * 3 + 2];
                 const float dx = rays_d[pt * 3], dy = rays_d[pt * 3 + 1], dz = rays_d[pt * 3 + 2];
@@ -289,13 +398,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
             }
         } else {
             const int64_t ray = tile / tiles_per_ray;
-            const int s0 = int(tile - ray * tiles_per_ray) * 64;
+            const int s0 = int(tile - ray * tiles_per_ray) * TP;
             const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
             float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
             const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // volume_renderer.py:230 (torch's 3-element norm)
             dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
 #pragma unroll
-            for (int set = 0; set < 2; ++set) {
+            for (int set = 0; set < NSETS; ++set) {
                 const float zz = zbuf[ray * z_stride + s0 + 32 * set + j];
                 const float px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
                 const float py = __fadd_rn(oy, __fmul_rn(zz, dy));
@@ -307,36 +416,52 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
             }
             f32x16 denc[1];
             encode_pe_doubling<4>(dx, dy, dz, h, denc);
-            pack_tile(denc[0], dpe[0]);  // both sets are samples of the same ray
-            dpe[1][0] = dpe[0][0], dpe[1][1] = dpe[0][1];
+            pack_tile(denc[0], dpe[0]);  // all sets are samples of the same ray
+#pragma unroll
+            for (int set = 1; set < NSETS; ++set) dpe[set][0] = dpe[0][0], dpe[set][1] = dpe[0][1];
         }
 
-        u32x4 XA[2][8][2], XB[2][8][2];
-        {
-            EpiPack e{XA, kActRelu};
-            bf_layer<8, 2, 0, 0, kBStepsL0>(st, lane, bias_h, pe, nullptr, nullptr, e);                    // pts_linears.0
-        }
+        BF_STAMP_AT(1);
+        u32x4 XA[NSETS][8][2], XB[NSETS][8][2];
+        f32x16 acc[2][NSETS];                 // accumulator blocks [ob & 1][set], shared by all layers (see bf_layer)
+        EpiPack<NSETS> toA{XA, kActRelu};     // the epilogue a layer writing XA leaves pending for its successor
+        EpiPack<NSETS> toB{XB, kActRelu};
+        bf_layer<NSETS, 8, 2, 0, 0, kBStepsL0, false>(st, lane, bias_h, pe, nullptr, nullptr, toA, acc, toA);     // pts_linears.0
+        BF_STAMP_AT(2);
         // pts1..7 + feature as 4 pairs (XA -> XB -> XA); pair 2 starts with the skip layer, the last layer of pair 3
         // is feature_linear (no activation)
         for (int p = 0; p < 4; ++p) {
             const float* b0 = bias_h + (2 * p + 1) * 256;
-            EpiPack e0{XB, kActRelu};
+#ifdef BF_STAMP
+            st.stamp_base = stamp_tile ? 16 + 20 * p : -1;
+#endif
+            // first layer of the pair: XA -> XB; the layer before it (pts0 or the pair before) left XA's block 7 pending
             if (p == 2)
-                bf_layer<8, 2, 8, 0, kBStepsSkip>(st, lane, b0, pe, XA, nullptr, e0);                      // cat([pe, h]) (network.py:58)
+                bf_layer<NSETS, 8, 2, 8, 0, kBStepsSkip, true>(st, lane, b0, pe, XA, nullptr, toB, acc, toA);     // cat([pe, h]) (network.py:58)
             else
-                bf_layer<8, 0, 8, 0, kBStepsHidden>(st, lane, b0, nullptr, XA, nullptr, e0);
-            EpiPack e1{XA, p == 3 ? kActNone : kActRelu};
-            bf_layer<8, 0, 8, 0, kBStepsHidden>(st, lane, b0 + 256, nullptr, XB, nullptr, e1);
+                bf_layer<NSETS, 8, 0, 8, 0, kBStepsHidden, true>(st, lane, b0, nullptr, XA, nullptr, toB, acc, toA);
+            BF_STAMP_AT(3 + 2 * p);
+#ifdef BF_STAMP
+            st.stamp_base = stamp_tile ? 26 + 20 * p : -1;
+#endif
+            toA.lim = p == 3 ? kActNone : kActRelu;                                                               // feature_linear: no activation
+            bf_layer<NSETS, 8, 0, 8, 0, kBStepsHidden, true>(st, lane, b0 + 256, nullptr, XB, nullptr, toA, acc, toB);
+            BF_STAMP_AT(4 + 2 * p);
+#ifdef BF_STAMP
+            st.stamp_base = -1;
+#endif
         }
         // XB = bf16(relu(h7)): alpha_linear, fp32 weights on the VALU
-        float sigma[2] = {0.f, 0.f};
+        float sigma[NSETS];
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set) sigma[set] = 0.f;
         {
             const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {
                 const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
 #pragma unroll
-                for (int set = 0; set < 2; ++set)
+                for (int set = 0; set < NSETS; ++set)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -347,27 +472,34 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16_kernel(const char* __restrict
                         }
             }
         }
-        // (Folding these dot products into the block epilogues of pts_linears.7 was measured: its layer body is shared
-        // with pts_linears.1 / .3, which then run the same 128 VALU instructions per block for nothing, and VALU work
-        // in the MFMAs' shadow is not free here -- 109.0 vs 106.5 ms per fine pass; a private copy of the body does
-        // not fit the instruction cache.)
+        // (Folding these dot products into the block epilogues of pts_linears.7 was measured on the NSETS = 2 form: its
+        // layer body is shared with pts_linears.1 / .3, which then run the same 128 VALU instructions per block for
+        // nothing -- 109.0 vs 106.5 ms per fine pass; a private copy of the body does not fit the instruction cache.)
         // Pin the alpha head HERE: LLVM otherwise sinks it to its use behind the views layer and keeps XB alive across
         // it in scratch -- and every scratch reload's vmcnt(0) also drains the LDS-DMA ring (measured: 42 % of the
         // kernel's wave time parked in s_waitcnt).
-        asm volatile("" : "+v"(sigma[0]), "+v"(sigma[1]));
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set) asm volatile("" : "+v"(sigma[set]));
+        BF_STAMP_AT(11);
         // views_linears.0 on cat([feature (XA, no activation), dir PE]) -> 128, relu, rgb_linear
-        EpiRgb er{cst + (kOffRgbW - kOffBias) + h * 16, {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}};
-        bf_layer<4, 0, 8, 1, kBStepsViewsPad>(st, lane, bias_h + 9 * 256, nullptr, XA, dpe, er);
+        EpiRgb<NSETS> er;
+        er.rw = cst + (kOffRgbW - kOffBias) + h * 16;
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set) er.acc[set][0] = er.acc[set][1] = er.acc[set][2] = 0.f;
+        bf_layer<NSETS, 4, 0, 8, 1, kBStepsViewsPad, true>(st, lane, bias_h + 9 * 256, nullptr, XA, dpe, er, acc, toA);
+        bf_finish<NSETS, 4>(er, acc);
+        BF_STAMP_AT(12);
         const float* rb = cst + (kOffRgbB - kOffBias);
         const float ab = cst[kOffAlphaB - kOffBias];
 #pragma unroll
-        for (int set = 0; set < 2; ++set) {
+        for (int set = 0; set < NSETS; ++set) {
             float r = er.acc[set][0], g = er.acc[set][1], b = er.acc[set][2];
             r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32);
             const float sg = sigma[set] + __shfl_xor(sigma[set], 32);
-            const int64_t dst = tile * 64 + 32 * set + j;
+            const int64_t dst = tile * TP + 32 * set + j;
             if (h == 0 && valid && (!POINTS || dst < n_points)) raw[dst] = make_float4(r + rb[0], g + rb[1], b + rb[2], sg + ab);
         }
+        BF_STAMP_AT(13);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
@@ -413,23 +545,33 @@ NRF_EXPORT int nrf_pack_weights_bf16(const float* const* w, const float* const* 
     return nrf_launch_status();
 }
 
-template <bool POINTS>
+// NRF_BF16_SETS=2 selects the round-1 tiling (diagnostics / A-B timing in one process); default 1.
+static int bf16_sets() {
+    static const int sets = [] {
+        const char* e = getenv("NRF_BF16_SETS");
+        return (e && e[0] == '2') ? 2 : 1;
+    }();
+    return sets;
+}
+
+template <bool POINTS, int NSETS>
 static int launch_bf16(const void* packed_bf16, const float* a, const float* b, const float* z, int64_t z_stride,
                        int tiles_per_ray, int64_t n_tiles, int64_t n_points, float* raw, nrf_stream_t stream) {
-    const int64_t groups = (n_tiles + 3) / 4;
+    constexpr int WAVES = 8 / NSETS;
+    const int64_t groups = (n_tiles + WAVES - 1) / WAVES;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
     static bool attr_set[64] = {};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16_kernel<POINTS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16_kernel<POINTS, NSETS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kBLdsBytes) != hipSuccess)
             return NRF_ERR_LAUNCH;
         attr_set[dev] = true;
     }
     const unsigned grid = unsigned(groups < cus ? groups : cus);
     nrf_launch_begin();
-    mlp_bf16_kernel<POINTS><<<dim3(grid), 256, kBLdsBytes, static_cast<hipStream_t>(stream)>>>(
+    mlp_bf16_kernel<POINTS, NSETS><<<dim3(grid), 64 * WAVES, kBLdsBytes, static_cast<hipStream_t>(stream)>>>(
         static_cast<const char*>(packed_bf16), a, b, z, z_stride, tiles_per_ray, n_tiles, groups, n_points,
         reinterpret_cast<float4*>(raw));
     return nrf_launch_status();
@@ -437,14 +579,16 @@ static int launch_bf16(const void* packed_bf16, const float* a, const float* b, 
 
 NRF_EXPORT int nrf_mlp_forward_rays_bf16(const void* packed_bf16, const float* rays_o, const float* rays_d, const float* z,
                                          int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream) {
-    if (n_rays < 0 || n_samples <= 0 || n_samples % 64 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
     if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
     if (n_rays == 0) return NRF_OK;
     if (!packed_bf16 || !rays_o || !rays_d || !z || !raw) return NRF_ERR_NULL;
     if (!nrf_aligned16(packed_bf16) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
     if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
-    const int tiles_per_ray = n_samples / 64;
-    return launch_bf16<false>(packed_bf16, rays_o, rays_d, z, z_stride, tiles_per_ray, n_rays * tiles_per_ray, 0, raw, stream);
+    if (bf16_sets() == 2 && n_samples % 64 == 0)
+        return launch_bf16<false, 2>(packed_bf16, rays_o, rays_d, z, z_stride, n_samples / 64, n_rays * (n_samples / 64), 0, raw, stream);
+    const int tiles_per_ray = n_samples / 32;
+    return launch_bf16<false, 1>(packed_bf16, rays_o, rays_d, z, z_stride, tiles_per_ray, n_rays * tiles_per_ray, 0, raw, stream);
 }
 
 // Network.forward on a flat batch with the bf16 MLP: pts (n, 3), dirs (n, 3) used as given.  raw: (n, 4).
@@ -454,5 +598,7 @@ NRF_EXPORT int nrf_mlp_forward_points_bf16(const void* packed_bf16, const float*
     if (n_points == 0) return NRF_OK;
     if (!packed_bf16 || !pts || !dirs || !raw) return NRF_ERR_NULL;
     if (!nrf_aligned16(packed_bf16) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
-    return launch_bf16<true>(packed_bf16, pts, dirs, nullptr, 0, 0, (n_points + 63) / 64, n_points, raw, stream);
+    if (bf16_sets() == 2)
+        return launch_bf16<true, 2>(packed_bf16, pts, dirs, nullptr, 0, 0, (n_points + 63) / 64, n_points, raw, stream);
+    return launch_bf16<true, 1>(packed_bf16, pts, dirs, nullptr, 0, 0, (n_points + 31) / 32, n_points, raw, stream);
 }
