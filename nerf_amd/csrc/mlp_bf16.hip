@@ -15,18 +15,13 @@
 // ping-pong between two register arrays.  The LDS ring moves 32-KiB chunks (one barrier per 2048 matrix cycles per
 // SIMD) and its LDS-DMA refills are spread over the chunk's steps.
 //
-// Two tilings of the same chain (template NSETS; every workgroup covers 256 points per pass of the weight stream):
-//   NSETS = 1 (default): EIGHT waves per workgroup, two per SIMD, each owning ONE 32-point set.  A wave's registers
-//     (two 64-register activation arrays, two accumulator blocks, encodings, the operand look-ahead) fit the 256
-//     architectural VGPRs a wave gets at two per SIMD, so nothing ever moves between VGPRs and AGPRs, and a wave's
-//     activation epilogues, LDS waits, encoding and heads run under its SIMD partner's MFMAs.
-//   NSETS = 2 (round 1, NRF_BF16_SETS=2): four waves, one per SIMD, each owning two 32-point sets that share every
-//     weight operand (one ds_read_b128 per 2 MFMAs).  It needs 486 registers, so half of the activations live in AGPRs
-//     and every layer pays VGPR<->AGPR copies plus un-hidden epilogues: the phase stamps of tools/ubench/bf16_phase.hip
-//     show 52 % of a tile's cycles in MFMAs.
+// Tiling (template NSETS = 2): four waves per workgroup, one per SIMD, each owning two 32-point sets that share every
+// weight operand (one ds_read_b128 per 2 MFMAs); a workgroup covers 256 points per pass of the weight stream.
+// NSETS = 1 -- eight waves, two per SIMD, one set each, everything in the 256 architectural VGPRs, no VGPR<->AGPR
+// copies -- was built and measured in round 2: 8 % fewer cycles, but twice the LDS read bytes per MFMA, and the chip
+// answered with a 9 % lower clock (1.72 vs 1.89 GHz, GRBM_GUI_ACTIVE): 10.99 vs 10.95 ms per 65,536-ray fine pass.  The
+// template parameter stays (the code is generic in it); only NSETS = 2 is instantiated.
 #include "mlp_chain.h"
-
-#include <cstdlib>
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -37,7 +32,11 @@ namespace {
 constexpr int kBChunkSteps = 32;                   // 1-KiB steps per ring chunk
 constexpr int kBChunkBytes = kBChunkSteps * 1024;  // 32 KiB
 constexpr int kBRing = 4;
-constexpr int kLook = 3;                           // LDS -> register look-ahead of the weight operands, in steps
+#ifndef BF_LOOK
+#define BF_LOOK 3
+#endif
+constexpr int kLook = BF_LOOK;                     // LDS -> register look-ahead of the weight operands, in steps
+constexpr int kWQ = kLook < 4 ? 4 : 8;             // register ring of those operands (power of two > kLook)
 constexpr int kBStepsL0 = 8 * 2 * 2;               // 8 out blocks x 2 PE k-blocks x 2 k16-steps
 constexpr int kBStepsHidden = 8 * 8 * 2;           // 128
 constexpr int kBStepsSkip = 8 * 10 * 2;            // 160: per output block 2 PE k-blocks then 8 hidden
@@ -106,7 +105,7 @@ struct BRing {
     char* smem;
     int pf_slot, rd_slot;
     const u32x4* rd;     // this lane's 16 B of step 0 of the chunk being read
-    u32x4 wq[4];         // weights of steps s .. s+2 (slot = step & 3), read kLook steps ahead of their MFMAs
+    u32x4 wq[kWQ];       // weights of steps s .. s+kLook-1 (slot = step % kWQ), read kLook steps ahead of their MFMAs
 #ifdef BF_STAMP
     int stamp_base;      // >= 0: bf_layer stamps the start of every output block at g_bf_stamps[.. + stamp_base + ob]
     int stamp_wave;
@@ -117,11 +116,9 @@ __device__ __forceinline__ void br_prefetch_piece(const BRing& st, int j) {
 #ifdef BF_ABL_NODMA  // timing-only ablation builds (tools/debug/bf16_ablate.py): results are wrong
     return;
 #endif
-#ifdef BF_STAMP  // the stamps' lane-0 stores make the compiler lose the uniformity of the slot index
+    // readfirstlane: the slot index is uniform, but under SGPR pressure the compiler may keep it in a VGPR, and the
+    // asm's M0 operand must be a scalar register (folds away when it already is one)
     glds16(st.gnext + j * 1024, __builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kBChunkBytes + j * 1024));
-#else
-    glds16(st.gnext + j * 1024, st.lds_base + unsigned(st.pf_slot) * kBChunkBytes + j * 1024);
-#endif
 }
 __device__ __forceinline__ void br_prefetch_advance(BRing& st) {
     const char* nx = st.gnext + kBChunkBytes;
@@ -135,7 +132,7 @@ __device__ __forceinline__ void br_prefetch_advance(BRing& st) {
 template <int PW>
 __device__ __forceinline__ void br_acquire(BRing& st, int lane) {
 #ifndef BF_ABL_NOBARRIER
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(2 * PW) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(2 * PW) : "memory");   // (dropping the lgkmcnt(0): no change, A/B in one process)
     __builtin_amdgcn_s_barrier();
 #endif
     st.rd_slot = st.rd_slot + 1 == kBRing ? 0 : st.rd_slot + 1;
@@ -188,15 +185,6 @@ __device__ unsigned long long g_bf_stamps[256 * 8 * 128];
 // (relu on the PACKED pairs, one v_pk_max_i16 against 0 or 0x80008000 -- both halves of the limit word matter --
 // gives the same bits with half the instructions, and measured 2 % SLOWER on the same box, 144.9 vs 141.5 ms per
 // frame: the activation then waits for the conversion instead of running ahead of it.  Not used.)
-__device__ __forceinline__ void act_pack(const f32x16& y, int lim, u32x4 out[2]) {
-    f32x16 v;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int bits = __float_as_int(y[t]);
-        v[t] = __int_as_float(bits > lim ? bits : lim);
-    }
-    pack_tile(v, out);
-}
 constexpr int kActRelu = 0, kActNone = int(0x80000000u);
 
 // Block epilogues come in SLICES.  A finished 32-row block needs 3 VALU instructions per packed output register
@@ -210,7 +198,7 @@ template <int NSETS>
 struct EpiPack {  // hidden layers: activate + pack block ob of every set into the next layer's input
     static constexpr int Q = 8 * NSETS;   // slices per block: one packed output register each
     u32x4 (*Xout)[8][2];
-    int lim;                              // kActRelu / kActNone: see act_pack
+    int lim;                              // kActRelu / kActNone
     __device__ __forceinline__ void begin(int) {}
     __device__ __forceinline__ void slice(int ob, const f32x16 (&y)[NSETS], int q) {
         const int set = q / 8, s = (q % 8) / 4, i = q % 4;
@@ -259,7 +247,7 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
     static_assert(NOB % 2 == 0, "the last block must leave its accumulators in acc[1], the next layer starts in acc[0]");
     static_assert(!PEND || (NHID == 8 && PE > S0), "a pending epilogue needs a layer that reads 8 input blocks");
     static_assert(NSPAD % kBChunkSteps == 0 && NSPAD >= NS && NSPAD - NS < kBChunkSteps, "layer padding");
-    static_assert(NS % 4 == 0 && (NS % kBChunkSteps == 0 || (NS % kBChunkSteps) % 4 == 0) && (NS % kBChunkSteps == 0 || NS % kBChunkSteps > kLook),
+    static_assert(NS % kWQ == 0 && (NS % kBChunkSteps == 0 || (NS % kBChunkSteps) % 4 == 0) && (NS % kBChunkSteps == 0 || NS % kBChunkSteps > kLook),
                   "register ring phase / tail length");
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
@@ -285,9 +273,9 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
                 const int cs = s % kBChunkSteps;                                        // position inside the ring chunk
                 const int cend = (s - cs + kBChunkSteps - 1) < NS - 1 ? (s - cs + kBChunkSteps - 1) : NS - 1;  // chunk's last step
                 const bool tail = cend - (s - cs) + 1 < kBChunkSteps;                   // padded (short) last chunk of the layer
-                const u32x4 w = st.wq[s & 3];
+                const u32x4 w = st.wq[s % kWQ];
                 const int r = s + kLook;
-                if (r <= cend) st.wq[r & 3] = st.rd[(cs + kLook) * 64];
+                if (r <= cend) st.wq[r % kWQ] = st.rd[(cs + kLook) * 64];
                 const bool slot = cs % GAP == 0;                                        // this chunk-time's refill pieces
                 const bool flush = tail && s == cend - kLook;                           // short chunk: issue what its steps never reach
                 if (slot || flush) {
@@ -301,7 +289,7 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (s == cend - kLook) br_acquire<PW>(st, lane);
-                if (r > cend) st.wq[r & 3] = st.rd[(r - cend - 1) * 64];
+                if (r > cend) st.wq[r % kWQ] = st.rd[(r - cend - 1) * 64];
                 // this step's share of the previous block's epilogue (own layer: block ob-1; block 0: the pending one)
                 if (sb >= S0) {
                     if (ob > 0) {
@@ -545,15 +533,6 @@ NRF_EXPORT int nrf_pack_weights_bf16(const float* const* w, const float* const* 
     return nrf_launch_status();
 }
 
-// NRF_BF16_SETS=2 selects the round-1 tiling (diagnostics / A-B timing in one process); default 1.
-static int bf16_sets() {
-    static const int sets = [] {
-        const char* e = getenv("NRF_BF16_SETS");
-        return (e && e[0] == '2') ? 2 : 1;
-    }();
-    return sets;
-}
-
 template <bool POINTS, int NSETS>
 static int launch_bf16(const void* packed_bf16, const float* a, const float* b, const float* z, int64_t z_stride,
                        int tiles_per_ray, int64_t n_tiles, int64_t n_points, float* raw, nrf_stream_t stream) {
@@ -579,16 +558,14 @@ static int launch_bf16(const void* packed_bf16, const float* a, const float* b, 
 
 NRF_EXPORT int nrf_mlp_forward_rays_bf16(const void* packed_bf16, const float* rays_o, const float* rays_d, const float* z,
                                          int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream) {
-    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 64 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
     if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
     if (n_rays == 0) return NRF_OK;
     if (!packed_bf16 || !rays_o || !rays_d || !z || !raw) return NRF_ERR_NULL;
     if (!nrf_aligned16(packed_bf16) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
     if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
-    if (bf16_sets() == 2 && n_samples % 64 == 0)
-        return launch_bf16<false, 2>(packed_bf16, rays_o, rays_d, z, z_stride, n_samples / 64, n_rays * (n_samples / 64), 0, raw, stream);
-    const int tiles_per_ray = n_samples / 32;
-    return launch_bf16<false, 1>(packed_bf16, rays_o, rays_d, z, z_stride, tiles_per_ray, n_rays * tiles_per_ray, 0, raw, stream);
+    const int tiles_per_ray = n_samples / 64;
+    return launch_bf16<false, 2>(packed_bf16, rays_o, rays_d, z, z_stride, tiles_per_ray, n_rays * tiles_per_ray, 0, raw, stream);
 }
 
 // Network.forward on a flat batch with the bf16 MLP: pts (n, 3), dirs (n, 3) used as given.  raw: (n, 4).
@@ -598,7 +575,5 @@ NRF_EXPORT int nrf_mlp_forward_points_bf16(const void* packed_bf16, const float*
     if (n_points == 0) return NRF_OK;
     if (!packed_bf16 || !pts || !dirs || !raw) return NRF_ERR_NULL;
     if (!nrf_aligned16(packed_bf16) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
-    if (bf16_sets() == 2)
-        return launch_bf16<true, 2>(packed_bf16, pts, dirs, nullptr, 0, 0, (n_points + 63) / 64, n_points, raw, stream);
-    return launch_bf16<true, 1>(packed_bf16, pts, dirs, nullptr, 0, 0, (n_points + 31) / 32, n_points, raw, stream);
+    return launch_bf16<true, 2>(packed_bf16, pts, dirs, nullptr, 0, 0, (n_points + 63) / 64, n_points, raw, stream);
 }

@@ -86,7 +86,7 @@ def test_bf16_argument_checks(dev):
     from nerf_amd import _lib
     L = _lib.lib()
     assert L.nrf_packed_bf16_bytes() == 1184 * 1024 + 3104 * 4
-    assert L.nrf_mlp_forward_rays_bf16(None, None, None, None, 0, 4, 80, None, None) == -2     # 80 % 32 != 0
+    assert L.nrf_mlp_forward_rays_bf16(None, None, None, None, 0, 4, 96, None, None) == -2     # 96 % 64 != 0
     assert L.nrf_mlp_forward_rays_bf16(None, None, None, None, 0, 0, 64, None, None) == 0      # empty batch
     assert L.nrf_mlp_forward_rays_bf16(None, None, None, None, 0, 4, 64, None, None) == -1
     from nerf_amd.config import default_cfg

@@ -1,6 +1,7 @@
 """Times nrf_mlp_forward_rays_bf16 from an arbitrary build of the library (ablation builds: results are wrong,
 only the time means something).  usage: bf16_ablate.py <lib.so> [<lib.so> ...]"""
 import ctypes as C
+import os
 import sys
 import time
 
@@ -20,6 +21,7 @@ shapes = [(256, 63)] + [(256, 256)] * 4 + [(256, 319)] + [(256, 256)] * 3 + [(1,
 ws = [torch.randn(s, device=dev) * 0.05 for s in shapes]
 bs = [torch.zeros(s[0], device=dev) for s in shapes]
 for path in sys.argv[1:]:
+    path = os.path.abspath(path)
     L = C.CDLL(path)
     L.nrf_packed_bf16_bytes.restype = C.c_int64
     packed = torch.zeros(L.nrf_packed_bf16_bytes(), dtype=torch.uint8, device=dev)
