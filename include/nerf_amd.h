@@ -105,6 +105,21 @@ int nrf_mlp_forward_rays_bf16(const void* packed_bf16, const float* rays_o, cons
 int nrf_mlp_forward_points_bf16(const void* packed_bf16, const float* pts, const float* dirs, int64_t n_points,
                                 float* raw, nrf_stream_t stream);
 
+/* ---- fp32-class MLP on the bf16 matrix cores ("bf16x3") ------------------------------------------------------------ */
+
+/* Same network and reference path again (network.py:49-74, 171-195, volume_renderer.py:227-231, 393-423).  Every fp32
+ * weight and every layer input is split into three bf16 terms (a = a0 + a1 + a2, 24 significand bits) and each product
+ * is the six v_mfma_f32_32x32x16_bf16 with i + j <= 2, fp32 accumulation; the dropped terms are 2^-24 of the product
+ * (fp32's own rounding unit).  fp32 biases and fp32 alpha / rgb heads.  Results are fp32-class (as close to a float64
+ * evaluation as the fp32 reference is: tests/test_gpu_bf16x3.py), at 6 / 16 of the fp32 MFMA time on paper.
+ * n_samples must be a multiple of 32. */
+int64_t nrf_packed_bf16x3_bytes(void);
+int nrf_pack_weights_bf16x3(const float* const* w, const float* const* b, void* packed_x3, nrf_stream_t stream);
+int nrf_mlp_forward_rays_bf16x3(const void* packed_x3, const float* rays_o, const float* rays_d, const float* z,
+                                int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream);
+int nrf_mlp_forward_points_bf16x3(const void* packed_x3, const float* pts, const float* dirs, int64_t n_points,
+                                  float* raw, nrf_stream_t stream);
+
 /* ---- alpha compositing: volume_renderer.py:222-224, 236-265 / 291-334 --------------- */
 
 /* sigma = relu(raw[...,3]); rgb = sigmoid(raw[...,:3]); delta = diff(z), last = 1e10;
@@ -305,6 +320,8 @@ int nrf_render(const nrf_render_args* args, nrf_stream_t stream);
 /* The same path with bf16 MLPs: packed_coarse / packed_fine are nrf_pack_weights_bf16 streams (cast to const float*),
  * everything else as above (compositing, resampling and all outputs stay fp32). */
 int nrf_render_bf16(const nrf_render_args* args, nrf_stream_t stream);
+/* ... and with the bf16x3 MLPs: packed_coarse / packed_fine are nrf_pack_weights_bf16x3 streams. */
+int nrf_render_bf16x3(const nrf_render_args* args, nrf_stream_t stream);
 
 
 /* ---- the whole forward path without any allocation ------------------------------------------------------------------

@@ -28,6 +28,8 @@ SYMBOLS = (
     "nrf_kilo_backward_workspace_bytes", "nrf_kilo_backward", "nrf_l2_reg",
     "nrf_kilo_record_floats", "nrf_kilo_cells_gather", "nrf_kilo_cells_scatter",
     "nrf_render_static",
+    "nrf_packed_bf16x3_bytes", "nrf_pack_weights_bf16x3", "nrf_mlp_forward_rays_bf16x3", "nrf_mlp_forward_points_bf16x3",
+    "nrf_render_bf16x3",
 )
 
 P = C.c_void_p
@@ -80,6 +82,16 @@ def lib() -> C.CDLL:
     L.nrf_render.argtypes = [C.POINTER(RenderArgs), P]
     L.nrf_render_bf16.argtypes = [C.POINTER(RenderArgs), P]
     L.nrf_render_bf16.restype = INT
+    L.nrf_render_bf16x3.argtypes = [C.POINTER(RenderArgs), P]
+    L.nrf_render_bf16x3.restype = INT
+    L.nrf_packed_bf16x3_bytes.restype = I64
+    L.nrf_packed_bf16x3_bytes.argtypes = []
+    L.nrf_pack_weights_bf16x3.restype = INT
+    L.nrf_pack_weights_bf16x3.argtypes = [P, P, P, P]
+    L.nrf_mlp_forward_rays_bf16x3.restype = INT
+    L.nrf_mlp_forward_rays_bf16x3.argtypes = [P, P, P, P, I64, I64, INT, P, P]
+    L.nrf_mlp_forward_points_bf16x3.restype = INT
+    L.nrf_mlp_forward_points_bf16x3.argtypes = [P, P, P, I64, P, P]
     L.nrf_render_static.argtypes = [C.POINTER(RenderArgs), P]
     L.nrf_render_static.restype = INT
     L.nrf_packed_bwd_floats.restype = I64

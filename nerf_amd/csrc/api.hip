@@ -46,7 +46,9 @@ NRF_EXPORT int64_t nrf_render_workspace_bytes(int64_t n_rays, int n_coarse, int 
     return Workspace(n_rays, n_coarse, n_importance).total;
 }
 
-static int render_path(const nrf_render_args* a, bool bf16, nrf_stream_t stream) {
+enum MlpKind { MLP_FP32 = 0, MLP_BF16 = 1, MLP_BF16X3 = 2 };
+
+static int render_path(const nrf_render_args* a, MlpKind kind, nrf_stream_t stream) {
     if (!a) return NRF_ERR_NULL;
     if (!a->packed_coarse || !a->packed_fine || !a->rays_o || !a->rays_d || !a->bins || !a->u || !a->u2 ||
         !a->coarse_rgb || !a->coarse_depth || !a->fine_rgb || !a->fine_depth || !a->fine_acc || !a->workspace)
@@ -75,8 +77,11 @@ static int render_path(const nrf_render_args* a, bool bf16, nrf_stream_t stream)
         zc_stride = nc;
     }
     auto mlp = [&](const float* packed, const float* z, int64_t z_stride, int n_samples) {
-        return bf16 ? nrf_mlp_forward_rays_bf16(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream)
-                    : nrf_mlp_forward_rays(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
+        if (kind == MLP_BF16)
+            return nrf_mlp_forward_rays_bf16(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
+        if (kind == MLP_BF16X3)
+            return nrf_mlp_forward_rays_bf16x3(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
+        return nrf_mlp_forward_rays(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
     };
     if ((st = mlp(a->packed_coarse, zc, zc_stride, nc))) return st;
     if ((st = nrf_composite(raw, zc, zc_stride, a->n_rays, nc, a->white_bkgd, a->coarse_rgb, a->coarse_depth, acc_c, w_c,
@@ -91,11 +96,12 @@ static int render_path(const nrf_render_args* a, bool bf16, nrf_stream_t stream)
                          nullptr, stream);
 }
 
-NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, false, stream); }
+NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, MLP_FP32, stream); }
 
 // Same path with both MLPs evaluated by nrf_mlp_forward_rays_bf16: packed_coarse / packed_fine point at
 // nrf_pack_weights_bf16 streams (BASELINE configs[4]).
-NRF_EXPORT int nrf_render_bf16(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, true, stream); }
+NRF_EXPORT int nrf_render_bf16(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, MLP_BF16, stream); }
+NRF_EXPORT int nrf_render_bf16x3(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, MLP_BF16X3, stream); }
 
 // ---- nrf_render without an allocation anywhere (no counterpart in the reference) ---------------------------------------
 // nrf_render's kernels need a workspace (raw, coarse weights, depths: ~4.4 KB per ray) that the caller normally brings.
@@ -130,5 +136,5 @@ NRF_EXPORT int nrf_render_static(const nrf_render_args* a, nrf_stream_t stream) 
     // Every workspace region is fully written by the stage that produces it before the stage that reads it
     // (raw by the MLP, weights / acc by compositing, depths by the resampler), for exactly n_rays rows: nothing has
     // to start at zero, so what the previous call left behind is never read.
-    return render_path(&b, false, stream);
+    return render_path(&b, MLP_FP32, stream);
 }

@@ -1,0 +1,394 @@
+// fp32-class 8x256 NeRF MLP on the bf16 matrix cores: every fp32 operand is split into THREE bf16 terms
+// (a = a0 + a1 + a2, a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 24 significand bits) and every product
+// W.x becomes the six MFMAs with i + j <= 2 (w2.x0, w0.x2, w1.x1, w1.x0, w0.x1, w0.x0; fp32 accumulate).  The dropped
+// terms are 2^-24 of the product, fp32's own rounding unit, so results are fp32-class (oracle restatement:
+// oracle/nerf_oracle.py:mlp_forward(split3=True); measured distance from a float64 evaluation <= the fp32
+// reference's own), while six v_mfma_f32_32x32x16_bf16 (192 cycles per 16 k) replace eight
+// v_mfma_f32_32x32x2_f32 (512 cycles): 2.67x the fp32 MFMA rate on paper.  Same reference path as mlp_fp32.hip
+// (volume_renderer.py:227-231, 393-423, network.py:49-74, 171-195, encoding/freq.py:31-32).
+//
+// Shape: the fp32 kernel's chain (mlp_chain.h: one wave = 32 points x 256 features, all 8 accumulator blocks Y of a
+// layer live, the next layer's input X made from Y just in time while output block 0 accumulates), with X held as
+// three bf16 B-fragment sets (192 registers) instead of fp32 (128), and the weight stream in 3-KiB steps
+// (hi | mid | lo fragment of one k16-step of one 32-row block) through the same LDS-DMA ring: 8-step = 24-KiB chunks,
+// 5 slots, one raw barrier per chunk, the 6 refill pieces of a wave in the 6 MFMA gaps of the hand-over step.
+// Heads (alpha 256->1, rgb 128->3) are fp32 VALU dot products on the fp32 accumulators, as in the fp32 kernel.
+#include "mlp_chain.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kXStepBytes = 3 * 1024;                 // hi | mid | lo A fragments of one k16-step
+constexpr int kXChunkSteps = 8;
+constexpr int kXChunkBytes = kXChunkSteps * kXStepBytes;   // 24 KiB
+constexpr int kXRing = 5;
+constexpr int kXPieces = kXChunkBytes / 1024 / 4;     // LDS-DMA pieces per wave per chunk: 6
+constexpr int kXStepsL0 = 8 * 2 * 2;                  // 8 out blocks x 2 PE k-blocks x 2 k16-steps
+constexpr int kXStepsHidden = 8 * 8 * 2;              // 128
+constexpr int kXStepsViews = 4 * 9 * 2;               // 72
+// stream order (steps): pts0, pts1..4, pts5 hidden part, pts5 PE pass, pts6, pts7, feature, views
+constexpr int kXLayerStep[11] = {0, 32, 160, 288, 416, 544, 672, 704, 832, 960, 1088};
+constexpr int kXStreamSteps = 1088 + kXStepsViews;    // 1160
+constexpr int kXChunks = kXStreamSteps / kXChunkSteps;  // 145
+static_assert(kXStreamSteps % kXChunkSteps == 0 && kXStepsL0 % kXChunkSteps == 0 && kXStepsHidden % kXChunkSteps == 0 &&
+              kXStepsViews % kXChunkSteps == 0, "layers must be whole chunks");
+constexpr int64_t kXSmallFloatOff = int64_t(kXStreamSteps) * kXStepBytes / 4;   // fp32 small block behind the stream
+constexpr int kXLdsConstOff = kXRing * kXChunkBytes;                             // 120 KiB
+constexpr int kXLdsBytes = kXLdsConstOff + kSmallFloats * 4;                     // + 12.1 KiB
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round to nearest even
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo(unsigned r) { return __uint_as_float(r << 16); }
+__device__ __forceinline__ float bf_hi(unsigned r) { return __uint_as_float(r & 0xffff0000u); }
+
+// a pair of fp32 values -> the packed pair of each of its three bf16 terms (residuals are exact in fp32)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = pk_bf16(a, b);
+    const float ra = __fsub_rn(a, bf_lo(p0)), rb = __fsub_rn(b, bf_hi(p0));
+    p1 = pk_bf16(ra, rb);
+    p2 = pk_bf16(__fsub_rn(ra, bf_lo(p1)), __fsub_rn(rb, bf_hi(p1)));
+}
+// a 32-row block held as 16 accumulator registers -> the B fragments [k16-step][term] of its three terms
+__device__ __forceinline__ void split_tile(const f32x16& v, u32x4 (&out)[2][3]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned p0, p1, p2;
+            split_pair(v[8 * s + 2 * i], v[8 * s + 2 * i + 1], p0, p1, p2);
+            out[s][0][i] = p0, out[s][1][i] = p1, out[s][2][i] = p2;
+        }
+}
+
+// ---- weight packing ------------------------------------------------------------------------
+struct XPackLayer {
+    const float* W;
+    unsigned short* dst;
+    int ldw, nob;
+    int pre_kb, hid_kb, post_kb;
+    int pre_L, post_L;
+    int pre_col0, hid_col0, post_col0;
+};
+__device__ __forceinline__ unsigned short bf_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ float bf_val(unsigned short b) { return __uint_as_float(unsigned(b) << 16); }
+
+__global__ void xpack_layer_kernel(XPackLayer p) {
+    const int nkb = p.pre_kb + p.hid_kb + p.post_kb;
+    const int total = p.nob * nkb * 2 * 512;  // weights (one thread writes the three terms of one weight)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
+    const int s2 = step & 1, kbpos = (step >> 1) % nkb, ob = (step >> 1) / nkb;
+    const int h = lane >> 5, t = 8 * s2 + jj;
+    const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
+    float v = 0.f;
+    if (kbpos < p.pre_kb) {
+        const int c = pe_col(kbpos * 16 + t, h, p.pre_L);
+        if (c >= 0) v = p.W[row + p.pre_col0 + c];
+    } else if (kbpos < p.pre_kb + p.hid_kb) {
+        v = p.W[row + p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
+    } else {
+        const int c = pe_col((kbpos - p.pre_kb - p.hid_kb) * 16 + t, h, p.post_L);
+        if (c >= 0) v = p.W[row + p.post_col0 + c];
+    }
+    const unsigned short b0 = bf_bits(v);
+    const float r1 = v - bf_val(b0);
+    const unsigned short b1 = bf_bits(r1);
+    const unsigned short b2 = bf_bits(r1 - bf_val(b1));
+    unsigned short* d = p.dst + int64_t(step) * (kXStepBytes / 2) + lane * 8 + jj;
+    d[0] = b0, d[512] = b1, d[1024] = b2;
+}
+
+// ---- LDS ring of the 3-term stream (mlp_chain.h's WeightStream with 3-KiB steps) -----------------
+struct XRing {
+    const char* gnext;   // per lane: this lane's 16 B of piece 6w of the next chunk to prefetch
+    const char* gbegin;
+    const char* gend;
+    unsigned lds_base;   // LDS byte address of smem + wave * 6 KiB (this wave fills pieces 6w..6w+5)
+    char* smem;
+    int pf_slot, rd_slot;
+    const u32x4* rd;     // this lane's 16 B of term 0 of step 0 of the chunk being read
+    u32x4 w[3];          // the three weight fragments of the next step to be multiplied (already read from LDS)
+};
+__device__ __forceinline__ void xr_piece(const XRing& st, int j) {
+    glds16(st.gnext + j * 1024, __builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kXChunkBytes + j * 1024));
+}
+__device__ __forceinline__ void xr_advance(XRing& st) {
+    const char* nx = st.gnext + kXChunkBytes;
+    st.gnext = nx == st.gend ? st.gbegin : nx;
+    asm volatile("" : "+v"(st.gnext));  // keep it a run-time value (see ws_prefetch_advance)
+    st.pf_slot = st.pf_slot + 1 == kXRing ? 0 : st.pf_slot + 1;
+}
+__device__ __forceinline__ void xr_acquire(XRing& st, int lane) {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(kXPieces * (kXRing - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = st.rd_slot + 1 == kXRing ? 0 : st.rd_slot + 1;
+    st.rd = reinterpret_cast<const u32x4*>(st.smem + st.rd_slot * kXChunkBytes) + lane;
+}
+__device__ __forceinline__ void xr_read(XRing& st, int step_in_chunk) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) st.w[t] = st.rd[(step_in_chunk * 3 + t) * 64];
+}
+__device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, char* smem, int wave, int lane) {
+    st.gbegin = stream_base + wave * (kXPieces * 1024) + lane * 16;
+    st.gend = st.gbegin + size_t(kXChunks) * kXChunkBytes;
+    st.gnext = st.gbegin;
+    st.smem = smem;
+    st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * unsigned(kXPieces * 1024));
+    st.pf_slot = 0;
+#pragma unroll
+    for (int i = 0; i < kXRing; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < kXPieces; ++jj) xr_piece(st, jj);
+        xr_advance(st);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kXPieces * (kXRing - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = 0;
+    st.rd = reinterpret_cast<const u32x4*>(smem) + lane;
+    xr_read(st, 0);
+}
+
+#define NRF_MFMA_X3(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// input ops: X[i] (three-term B fragments) from Y[i] of the previous layer
+struct OpSplit {      // no activation (feature -> views)
+    __device__ __forceinline__ void operator()(int, const f32x16& y, u32x4 (&x)[2][3]) { split_tile(y, x); }
+};
+struct OpReluSplit {  // hidden layers
+    __device__ __forceinline__ void operator()(int, const f32x16& y, u32x4 (&x)[2][3]) { split_tile(relu16(y), x); }
+};
+struct OpReluSplitAlpha {  // feature_linear's input relu(h7) also feeds alpha_linear (256 -> 1, fp32 weights, VALU)
+    const float* aw;       // cst + alpha weights + h * 16
+    float sigma;
+    __device__ __forceinline__ void operator()(int kb, const f32x16& y, u32x4 (&x)[2][3]) {
+        const f32x16 hx = relu16(y);
+        const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], hx[t], sigma);
+        split_tile(hx, x);
+    }
+};
+
+// One GEMM layer of the chain for this wave's 32 points (mlp_chain.h: mfma_layer): Y[ob] = init + sum_k W . [pre, X, post],
+// X[i] = op(Y[i] of the previous layer) made one k-block ahead of its use while output block 0 accumulates.
+template <int NOB, int NPRE, int NHID, int NPOST, int INIT, class InOp>
+__device__ __forceinline__ void x3_layer(XRing& st, int lane, const float* bias_h, const u32x4 (*pre)[2][3],
+                                         u32x4 (*X)[2][3], const u32x4 (*post)[2][3], f32x16* Y, InOp& op) {
+    constexpr int NKB = NPRE + NHID + NPOST;
+    constexpr int NS = NOB * NKB * 2;
+    static_assert(NS % kXChunkSteps == 0, "layer must be a whole number of chunks");
+    if (NHID > 0) op(0, Y[0], X[0]);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        if (INIT == INIT_BIAS) Y[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            // the next k-block's input, made under this k-block's 12 MFMAs
+            if (ob == 0 && kb + 1 > NPRE && kb + 1 < NPRE + NHID && kb + 1 - NPRE > 0) op(kb + 1 - NPRE, Y[kb + 1 - NPRE], X[kb + 1 - NPRE]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int s = (ob * NKB + kb) * 2 + s2;
+                const bool hand = (s + 1) % kXChunkSteps == 0;
+                const u32x4 w0 = st.w[0], w1 = st.w[1], w2 = st.w[2];
+                if (hand) xr_acquire(st, lane);
+                xr_read(st, (s + 1) % kXChunkSteps);
+                const u32x4* x = kb < NPRE ? pre[kb][s2] : (kb < NPRE + NHID ? X[kb - NPRE][s2] : post[kb - NPRE - NHID][s2]);
+                // small terms first; all six accumulate into the same block (a dependent chain issues at full rate)
+                Y[ob] = NRF_MFMA_X3(w2, x[0], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 0); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA_X3(w0, x[2], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 1); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA_X3(w1, x[1], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 2); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA_X3(w1, x[0], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 3); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA_X3(w0, x[1], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 4); __builtin_amdgcn_sched_barrier(0); }
+                Y[ob] = NRF_MFMA_X3(w0, x[0], Y[ob]);
+                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 5); xr_advance(st); __builtin_amdgcn_sched_barrier(0); }
+            }
+        }
+    }
+}
+
+// Persistent, one 4-wave workgroup per CU, one wave per SIMD, a wave's tile = 32 points (mlp_fp32.hip's tiling).
+__global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restrict__ packed, const float* __restrict__ a0,
+                                                            const float* __restrict__ a1, const float* __restrict__ zbuf,
+                                                            int64_t z_stride, int tiles_per_ray, int rays_mode,
+                                                            int64_t n_points, int64_t n_groups, float4* __restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    {
+        const float4* src = reinterpret_cast<const float4*>(packed + kXSmallFloatOff * 4);
+        float4* dst = reinterpret_cast<float4*>(smem + kXLdsConstOff);
+        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* cst = reinterpret_cast<const float*>(smem + kXLdsConstOff);
+    const float* bias_h = cst + h * 16;
+
+    XRing st;
+    xr_start(st, packed, smem, wave, lane);
+
+    for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+        const int64_t tile = tg * 4 + wave;
+        int64_t pidx = tile * 32 + j;
+        const bool valid = pidx < n_points;
+        if (!valid) pidx = n_points - 1;
+        float px, py, pz, dx, dy, dz;
+        if (rays_mode) {
+            const int64_t tile_c = pidx / 32;
+            const int64_t ray = tile_c / tiles_per_ray;
+            const int s0 = int(tile_c - ray * tiles_per_ray) * 32;
+            const float ox = a0[ray * 3 + 0], oy = a0[ray * 3 + 1], oz = a0[ray * 3 + 2];
+            dx = a1[ray * 3 + 0], dy = a1[ray * 3 + 1], dz = a1[ray * 3 + 2];
+            const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // volume_renderer.py:230 (torch's 3-element norm)
+            dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
+            const float zz = zbuf[ray * z_stride + s0 + (valid ? j : int(pidx & 31))];
+            px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
+            py = __fadd_rn(oy, __fmul_rn(zz, dy));
+            pz = __fadd_rn(oz, __fmul_rn(zz, dz));
+        } else {
+            px = a0[pidx * 3 + 0], py = a0[pidx * 3 + 1], pz = a0[pidx * 3 + 2];
+            dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
+        }
+        u32x4 pe[2][2][3], dpe[1][2][3];
+        split_tile(encode_block<10, 0>(px, py, pz, h), pe[0]);
+        split_tile(encode_block<10, 1>(px, py, pz, h), pe[1]);
+        split_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[0]);
+
+        u32x4 X[8][2][3];
+        f32x16 Y[8];
+        OpSplit op_none;
+        OpReluSplit op_relu;
+        x3_layer<8, 2, 0, 0, INIT_BIAS>(st, lane, bias_h, pe, X, nullptr, Y, op_none);             // pts_linears.0
+        for (int li = 1; li <= 7; ++li) {                                                           // pts 1..7
+            x3_layer<8, 0, 8, 0, INIT_BIAS>(st, lane, bias_h + li * 256, nullptr, X, nullptr, Y, op_relu);
+            if (li == 5)  // skip: cat([pe, h]) (network.py:58) = the hidden part above + this PE pass on top
+                x3_layer<8, 2, 0, 0, INIT_ACCUM>(st, lane, nullptr, pe, X, nullptr, Y, op_none);
+        }
+        OpReluSplitAlpha op_alpha{cst + (kOffAlphaW - kOffBias) + h * 16, 0.f};
+        x3_layer<8, 0, 8, 0, INIT_BIAS>(st, lane, bias_h + 8 * 256, nullptr, X, nullptr, Y, op_alpha);  // feature_linear (+ alpha)
+        float sigma = op_alpha.sigma;
+        asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
+        x3_layer<4, 0, 8, 1, INIT_BIAS>(st, lane, bias_h + 9 * 256, nullptr, X, dpe, Y, op_none);   // views_linears.0
+        float r = 0.f, g = 0.f, b = 0.f;
+        {
+            const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const f32x16 hv = relu16(Y[kb]);
+                const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
+                const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
+                const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    r = fmaf(w0[t], hv[t], r);
+                    g = fmaf(w1[t], hv[t], g);
+                    b = fmaf(w2[t], hv[t], b);
+                }
+            }
+        }
+        r += __shfl_xor(r, 32);
+        g += __shfl_xor(g, 32);
+        b += __shfl_xor(b, 32);
+        sigma += __shfl_xor(sigma, 32);
+        if (h == 0 && valid) {
+            const float* rb = cst + (kOffRgbB - kOffBias);
+            raw[pidx] = make_float4(r + rb[0], g + rb[1], b + rb[2], sigma + cst[kOffAlphaB - kOffBias]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+}
+
+int launch_x3(const void* packed, const float* a0, const float* a1, const float* z, int64_t z_stride, int tiles_per_ray,
+              int rays_mode, int64_t n_points, float* raw, hipStream_t stream) {
+    const int64_t tiles = (n_points + 31) / 32;
+    const int64_t groups = (tiles + 3) / 4;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    static bool attr_set[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kXLdsBytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const unsigned grid = unsigned(groups < cus ? groups : cus);
+    nrf_launch_begin();
+    mlp_bf16x3_kernel<<<dim3(grid), 256, kXLdsBytes, stream>>>(static_cast<const char*>(packed), a0, a1, z, z_stride,
+                                                               tiles_per_ray, rays_mode, n_points, groups,
+                                                               reinterpret_cast<float4*>(raw));
+    return nrf_launch_status();
+}
+
+}  // namespace
+
+NRF_EXPORT int64_t nrf_packed_bf16x3_bytes(void) { return kXSmallFloatOff * 4 + int64_t(kSmallFloats) * 4; }
+
+NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const* b, void* packed, nrf_stream_t stream_) {
+    if (!w || !b || !packed) return NRF_ERR_NULL;
+    for (int i = 0; i < NRF_NUM_LAYERS; ++i)
+        if (!w[i] || !b[i]) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned short* base = static_cast<unsigned short*>(packed);
+    nrf_launch_begin();
+    auto launch = [&](XPackLayer p, int step0) {
+        p.dst = base + int64_t(step0) * (kXStepBytes / 2);
+        const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
+        xpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+    };
+    launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0}, kXLayerStep[0]);
+    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kXLayerStep[l]);
+    // network.py:58 cat([input_pts, h]): hidden columns 63..318 as a plain layer, then the PE columns 0..62 accumulate
+    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0}, kXLayerStep[5]);
+    launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0}, kXLayerStep[6]);
+    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kXLayerStep[7]);
+    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kXLayerStep[8]);
+    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kXLayerStep[9]);      // feature_linear
+    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256}, kXLayerStep[10]);   // views_linears.0
+    PackSmall s;
+    for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
+    s.bias[8] = b[8];
+    s.bias[9] = b[10];
+    s.alpha_w = w[9];
+    s.alpha_b = b[9];
+    s.rgb_w = w[11];
+    s.rgb_b = b[11];
+    s.packed = static_cast<float*>(packed);
+    s.small_shift = kXSmallFloatOff - kOffBias;
+    pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_mlp_forward_rays_bf16x3(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                                           int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (!packed || !rays_o || !rays_d || !z || !raw) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
+    return launch_x3(packed, rays_o, rays_d, z, z_stride, n_samples / 32, 1, n_rays * n_samples, raw,
+                     static_cast<hipStream_t>(stream));
+}
+
+NRF_EXPORT int nrf_mlp_forward_points_bf16x3(const void* packed, const float* pts, const float* dirs, int64_t n_points,
+                                             float* raw, nrf_stream_t stream) {
+    if (n_points < 0 || n_points > (int64_t(1) << 40)) return NRF_ERR_SHAPE;
+    if (n_points == 0) return NRF_OK;
+    if (!packed || !pts || !dirs || !raw) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    return launch_x3(packed, pts, dirs, nullptr, 0, 1, 0, n_points, raw, static_cast<hipStream_t>(stream));
+}

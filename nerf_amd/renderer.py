@@ -33,6 +33,11 @@ def near_far_table(near: float, far: float, n: int) -> np.ndarray:
     return (f(near) * (f(1.0) - s) + f(far) * s).astype(f)
 
 
+_PACK = {"fp32": ops.pack_weights, "bf16": ops.pack_weights_bf16, "bf16x3": ops.pack_weights_bf16x3}
+_MLP_RAYS = {"fp32": ops.mlp_forward_rays, "bf16": ops.mlp_forward_rays_bf16, "bf16x3": ops.mlp_forward_rays_bf16x3}
+_MLP_POINTS = {"fp32": ops.mlp_forward_points, "bf16": ops.mlp_forward_points_bf16, "bf16x3": ops.mlp_forward_points_bf16x3}
+
+
 class _RenderTrainFn(torch.autograd.Function):
     """Coarse + fine render whose backward runs the HIP backward kernels.
 
@@ -81,7 +86,8 @@ class _RenderTrainFn(torch.autograd.Function):
 
 
 class Renderer(nn.Module):
-    """``mlp_dtype``: "fp32" (default, the reference's precision) or "bf16" (BASELINE configs[4]: the MLP on the bf16
+    """``mlp_dtype``: "fp32" (default, the reference's precision), "bf16x3" (fp32-class results from three-term bf16
+    operand splits on the bf16 matrix cores, inference only) or "bf16" (BASELINE configs[4]: the MLP on the bf16
     matrix cores, inference only; ``cfg.task_arg.mlp_dtype`` is read when the argument is None)."""
 
     def __init__(self, net, cfg=None, mlp_dtype: str | None = None):
@@ -103,8 +109,8 @@ class Renderer(nn.Module):
         self.far = ta.far
         self.chunk_size = ta.chunk_size if getattr(ta, "chunk_size", 0) > 0 else 1024
         self.mlp_dtype = mlp_dtype or getattr(ta, "mlp_dtype", "fp32")
-        if self.mlp_dtype not in ("fp32", "bf16"):
-            raise NrfError(f"mlp_dtype {self.mlp_dtype!r}: expected 'fp32' or 'bf16'")
+        if self.mlp_dtype not in ("fp32", "bf16", "bf16x3"):
+            raise NrfError(f"mlp_dtype {self.mlp_dtype!r}: expected 'fp32', 'bf16' or 'bf16x3'")
         if self.mlp_dtype == "bf16" and (self.N_samples % 64 or (self.N_samples + self.N_importance) % 64):
             raise NrfError("the bf16 MLP kernel needs sample counts that are multiples of 64")
         if self.raw_noise_std and self.raw_noise_std > 0:
@@ -189,9 +195,8 @@ class Renderer(nn.Module):
             n = int(pts.shape[0])
             self.last_num_samples += n
             if n:
-                bf16 = self.mlp_dtype == "bf16"
-                fwd = ops.mlp_forward_points_bf16 if bf16 else ops.mlp_forward_points
-                raw = fwd(self._packed_model("model", dev, bf16), pts, d.index_select(0, ray_idx.long()))
+                fwd = _MLP_POINTS[self.mlp_dtype]
+                raw = fwd(self._packed_model("model", dev, self.mlp_dtype), pts, d.index_select(0, ray_idx.long()))
             else:
                 raw = torch.empty((0, 4), dtype=torch.float32, device=dev)
             return kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.early_stop_eps, self.white_bkgd > 0)
@@ -202,7 +207,8 @@ class Renderer(nn.Module):
                 "rgb_map": rgb, "depth_map": depth, "acc_map": acc}
 
     # ---- weights ---------------------------------------------------------------------
-    def _packed_model(self, name: str, device, bf16: bool = False) -> torch.Tensor:
+    def _packed_model(self, name: str, device, kind="fp32") -> torch.Tensor:
+        kind = {True: "bf16", False: "fp32"}.get(kind, kind)
         model = getattr(self.net, name)
         params = []
         for ln in ops.LAYER_NAMES:
@@ -211,14 +217,14 @@ class Renderer(nn.Module):
                 mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
             params += [mod.weight, mod.bias]
         key = tuple((p.data_ptr(), p._version) for p in params) + (str(device),)
-        slot = name + (":bf16" if bf16 else "")
+        slot = name + ("" if kind == "fp32" else ":" + kind)
         hit = self._packed.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
         buf = hit[1] if hit is not None and hit[1].device == torch.device(device) else None
         ws = [p if p.device == torch.device(device) else p.to(device) for p in params[0::2]]
         bs = [p if p.device == torch.device(device) else p.to(device) for p in params[1::2]]
-        buf = (ops.pack_weights_bf16 if bf16 else ops.pack_weights)(ws, bs, out=buf)
+        buf = _PACK[kind](ws, bs, out=buf)
         self._packed[slot] = (key, buf)
         return buf
 
@@ -303,10 +309,9 @@ class Renderer(nn.Module):
         nc = self.N_samples
         if self._bins is None or self._bins.device != dev:
             self._bins = torch.from_numpy(near_far_table(self.near, self.far, nc)).to(dev)
-        bf16 = self.mlp_dtype == "bf16"
-        mlp = ops.mlp_forward_rays_bf16 if bf16 else ops.mlp_forward_rays
-        pc = self._packed_model("model", dev, bf16)
-        pf = self._packed_model("model_fine", dev, bf16)
+        mlp = _MLP_RAYS[self.mlp_dtype]
+        pc = self._packed_model("model", dev, self.mlp_dtype)
+        pf = self._packed_model("model_fine", dev, self.mlp_dtype)
         white = self.white_bkgd > 0
 
         def stage(name, fn, *a, **k):
@@ -339,9 +344,8 @@ class Renderer(nn.Module):
         nc, ni = self.N_samples, self.N_importance
         if self._bins is None or self._bins.device != dev:
             self._bins = torch.from_numpy(near_far_table(self.near, self.far, nc)).to(dev)
-        bf16 = self.mlp_dtype == "bf16"
-        pc = self._packed_model("model", dev, bf16)
-        pf = self._packed_model("model_fine", dev, bf16)
+        pc = self._packed_model("model", dev, self.mlp_dtype)
+        pf = self._packed_model("model_fine", dev, self.mlp_dtype)
         c_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
         c_depth = torch.empty((R,), dtype=torch.float32, device=dev)
         f_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
@@ -368,7 +372,8 @@ class Renderer(nn.Module):
                 a.coarse_rgb, a.coarse_depth = c_rgb[r0:].data_ptr(), c_depth[r0:].data_ptr()
                 a.fine_rgb, a.fine_depth, a.fine_acc = f_rgb[r0:].data_ptr(), f_depth[r0:].data_ptr(), f_acc[r0:].data_ptr()
                 a.workspace, a.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
-                check((L.nrf_render_bf16 if bf16 else L.nrf_render)(C.byref(a), stream), "nrf_render")
+                entry = {"fp32": L.nrf_render, "bf16": L.nrf_render_bf16, "bf16x3": L.nrf_render_bf16x3}[self.mlp_dtype]
+                check(entry(C.byref(a), stream), "nrf_render")
         return {
             "coarse_rgb_map": c_rgb, "coarse_depth_map": c_depth,
             "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc,

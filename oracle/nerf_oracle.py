@@ -109,7 +109,28 @@ def _q_bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Tensor, bf16: bool = False) -> torch.Tensor:
+def _split3(t: torch.Tensor):
+    """t = t0 + t1 + t2 with three bf16-representable terms (the residuals are exact in fp32): what the bf16x3 kernel
+    (mlp_bf16x3.hip) feeds the bf16 matrix cores."""
+    t0 = _q_bf16(t)
+    r = t - t0
+    t1 = _q_bf16(r)
+    return t0, t1, _q_bf16(r - t1)
+
+
+def _linear_split3(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """One layer of nrf_mlp_forward_rays_bf16x3: the six partial products with i + j <= 2 (each product of two bf16
+    values is exact in fp32), accumulated in fp32, small terms first, plus the fp32 bias."""
+    hs, ws = _split3(h), _split3(w)
+    acc = None
+    for i, j in ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)):       # (x term, w term)
+        p = F.linear(hs[i], ws[j])
+        acc = p if acc is None else acc + p
+    return acc + b
+
+
+def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Tensor, bf16: bool = False,
+                split3: bool = False) -> torch.Tensor:
     """``NeRF.forward`` (network.py:49-74): raw ``[r, g, b, sigma]`` per point, no activation.
 
     ``bf16=True`` restates the numerics of nrf_mlp_forward_rays_bf16 (mlp_bf16.hip): the weights and the input of
@@ -119,6 +140,8 @@ def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Te
 
     def lin(name, h, mfma=True):
         w = sd[f"{prefix}.{name}.weight"]
+        if split3 and mfma:       # ``split3=True``: the bf16x3 kernel's rule; the alpha / rgb heads stay fp32 (VALU)
+            return _linear_split3(h, w, sd[f"{prefix}.{name}.bias"])
         return F.linear(q(h), q(w), sd[f"{prefix}.{name}.bias"]) if mfma else F.linear(h, w, sd[f"{prefix}.{name}.bias"])
 
     h = emb_pts
@@ -135,7 +158,7 @@ def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Te
 
 
 def network_forward(sd: dict, pts: torch.Tensor, dirs: torch.Tensor, model: str = "",
-                    chunk: int = 65536, dtype=None, bf16: bool = False) -> torch.Tensor:
+                    chunk: int = 65536, dtype=None, bf16: bool = False, split3: bool = False) -> torch.Tensor:
     """``Network.forward`` (network.py:171-195). ``pts`` (R,S,3) with ``dirs`` (R,3), or
     ``pts`` (P,3) with ``dirs`` (P,3).  Returns (..., 4).
 
@@ -152,7 +175,7 @@ def network_forward(sd: dict, pts: torch.Tensor, dirs: torch.Tensor, model: str 
     for i in range(0, flat.shape[0], chunk):
         e = pos_enc(flat[i:i + chunk], 10)
         ed = pos_enc(dflat[i:i + chunk], 4)
-        outs.append(mlp_forward(sd, prefix, e, ed, bf16))
+        outs.append(mlp_forward(sd, prefix, e, ed, bf16, split3))
     out = torch.cat(outs, 0)
     return out.reshape(list(pts.shape[:-1]) + [4])
 
