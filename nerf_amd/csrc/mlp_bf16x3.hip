@@ -73,6 +73,7 @@ struct XPackLayer {
     int pre_kb, hid_kb, post_kb;
     int pre_L, post_L;
     int pre_col0, hid_col0, post_col0;
+    int pair01;   // hidden-type layers: the stream opens with blocks 0 and 1 interleaved, [kb][ob in {0,1}][s2]
 };
 __device__ __forceinline__ unsigned short bf_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float bf_val(unsigned short b) { return __uint_as_float(unsigned(b) << 16); }
@@ -83,7 +84,8 @@ __global__ void xpack_layer_kernel(XPackLayer p) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
-    const int s2 = step & 1, kbpos = (step >> 1) % nkb, ob = (step >> 1) / nkb;
+    int s2 = step & 1, kbpos = (step >> 1) % nkb, ob = (step >> 1) / nkb;
+    if (p.pair01 && step < 4 * nkb) kbpos = step >> 2, ob = (step >> 1) & 1;
     const int h = lane >> 5, t = 8 * s2 + jj;
     const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
     float v = 0.f;
@@ -157,64 +159,123 @@ __device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, cha
 #define NRF_MFMA_X3(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-// input ops: X[i] (three-term B fragments) from Y[i] of the previous layer
-struct OpSplit {      // no activation (feature -> views)
-    __device__ __forceinline__ void operator()(int, const f32x16& y, u32x4 (&x)[2][3]) { split_tile(y, x); }
-};
-struct OpReluSplit {  // hidden layers
-    __device__ __forceinline__ void operator()(int, const f32x16& y, u32x4 (&x)[2][3]) { split_tile(relu16(y), x); }
-};
-struct OpReluSplitAlpha {  // feature_linear's input relu(h7) also feeds alpha_linear (256 -> 1, fp32 weights, VALU)
-    const float* aw;       // cst + alpha weights + h * 16
+constexpr int kActRelu = 0, kActNone = int(0x80000000u);
+
+// Input op of a hidden-type layer: X[kb] (three-term B fragments) from Y[kb] of the previous layer, in eight slices of
+// one register pair each (relu as max(bits, lim): lim = 0, or INT_MIN for "no activation"; 15 VALU instructions per
+// slice).  The layer whose input is relu(h7) (feature_linear) also feeds alpha_linear (256 -> 1, fp32 weights, VALU).
+struct OpIn {
+    int lim;
+    bool alpha;        // run-time, uniform
+    const float* aw;   // cst + alpha weights + h * 16
     float sigma;
-    __device__ __forceinline__ void operator()(int kb, const f32x16& y, u32x4 (&x)[2][3]) {
-        const f32x16 hx = relu16(y);
-        const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
+    __device__ __forceinline__ void begin(int kb, const f32x16& y) {
+        if (alpha) {
+            const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
+            const f32x16 hx = relu16(y);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], hx[t], sigma);
-        split_tile(hx, x);
+            for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], hx[t], sigma);
+        }
+    }
+    __device__ __forceinline__ void pair(const f32x16& y, u32x4 (&x)[2][3], int q) {
+        const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
+        unsigned p0, p1, p2;
+        split_pair(__int_as_float(b0 > lim ? b0 : lim), __int_as_float(b1 > lim ? b1 : lim), p0, p1, p2);
+        x[q / 4][0][q % 4] = p0, x[q / 4][1][q % 4] = p1, x[q / 4][2][q % 4] = p2;
     }
 };
 
-// One GEMM layer of the chain for this wave's 32 points (mlp_chain.h: mfma_layer): Y[ob] = init + sum_k W . [pre, X, post],
-// X[i] = op(Y[i] of the previous layer) made one k-block ahead of its use while output block 0 accumulates.
-template <int NOB, int NPRE, int NHID, int NPOST, int INIT, class InOp>
-__device__ __forceinline__ void x3_layer(XRing& st, int lane, const float* bias_h, const u32x4 (*pre)[2][3],
-                                         u32x4 (*X)[2][3], const u32x4 (*post)[2][3], f32x16* Y, InOp& op) {
-    constexpr int NKB = NPRE + NHID + NPOST;
-    constexpr int NS = NOB * NKB * 2;
-    static_assert(NS % kXChunkSteps == 0, "layer must be a whole number of chunks");
-    if (NHID > 0) op(0, Y[0], X[0]);
+// One k16-step of the stream: the six MFMAs of one (output block, k16) pair into `y`; `hook(m)` runs after MFMA m.
+// The ring hand-over (acquire + the wave's 6 refill pieces, one per MFMA gap) rides on a chunk's last step.
+template <class Hook>
+__device__ __forceinline__ void x3_step(XRing& st, int lane, int s /* stream step inside the layer */, f32x16& y,
+                                        const u32x4* x, Hook&& hook) {
+    const bool hand = (s + 1) % kXChunkSteps == 0;
+    const u32x4 w0 = st.w[0], w1 = st.w[1], w2 = st.w[2];
+    if (hand) xr_acquire(st, lane);
+    xr_read(st, (s + 1) % kXChunkSteps);
+    // small terms first; all six accumulate into the same block (a dependent chain issues at full rate)
+    y = NRF_MFMA_X3(w2, x[0], y);
+    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 0); __builtin_amdgcn_sched_barrier(0); }
+    hook(0);
+    y = NRF_MFMA_X3(w0, x[2], y);
+    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 1); __builtin_amdgcn_sched_barrier(0); }
+    hook(1);
+    y = NRF_MFMA_X3(w1, x[1], y);
+    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 2); __builtin_amdgcn_sched_barrier(0); }
+    hook(2);
+    y = NRF_MFMA_X3(w1, x[0], y);
+    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 3); __builtin_amdgcn_sched_barrier(0); }
+    hook(3);
+    y = NRF_MFMA_X3(w0, x[1], y);
+    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 4); __builtin_amdgcn_sched_barrier(0); }
+    hook(4);
+    y = NRF_MFMA_X3(w0, x[0], y);
+    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 5); xr_advance(st); __builtin_amdgcn_sched_barrier(0); }
+    hook(5);
+}
+
+// Encoding-only layer (pts_linears.0, and the skip layer's PE pass which ACCUMULATES onto pts_linears.5's hidden part):
+// Y[ob] = (accum ? Y[ob] : bias) + W . pe.  `accum` is a run-time flag so both uses share one body.
+__device__ __forceinline__ void x3_pe_layer(XRing& st, int lane, const float* bias_h, bool accum, const u32x4 (*pe)[2][3],
+                                            f32x16* Y) {
+    static_assert(kXStepsL0 % kXChunkSteps == 0, "layer must be a whole number of chunks");
+    auto none = [](int) {};
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        if (INIT == INIT_BIAS) Y[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+    for (int ob = 0; ob < 8; ++ob) {
+        const f32x16 bias = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            // the next k-block's input, made under this k-block's 12 MFMAs
-            if (ob == 0 && kb + 1 > NPRE && kb + 1 < NPRE + NHID && kb + 1 - NPRE > 0) op(kb + 1 - NPRE, Y[kb + 1 - NPRE], X[kb + 1 - NPRE]);
+        for (int t = 0; t < 16; ++t) Y[ob][t] = accum ? Y[ob][t] : bias[t];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) x3_step(st, lane, (ob * 2 + kb) * 2 + s2, Y[ob], pe[kb][s2], none);
+    }
+}
+
+// Hidden-type layer: Y[ob] = bias + W . [X (8 k-blocks), post], X[kb] = op(Y[kb] of the previous layer).
+// Making one X[kb] is 120 VALU instructions, more than the 12 MFMAs of one (block, k-block) can cover, so the layer
+// opens with output blocks 0 AND 1 accumulated together (stream order [kb][ob in {0,1}][s2] for that part, see
+// xpack_layer_kernel): X[kb+1] is made in eight slices under the 24 MFMAs of k-block kb.  Block 1 accumulates into the
+// spare block Z because the previous layer's Y[1] is still needed (it becomes X[1] during k-block 0).
+template <int NOB, int NPOST>
+__device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float* bias_h, u32x4 (*X)[2][3],
+                                                const u32x4 (*post)[2][3], f32x16* Y, f32x16& Z, OpIn& op) {
+    constexpr int NKB = 8 + NPOST;
+    static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
+    auto none = [](int) {};
+    op.begin(0, Y[0]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) op.pair(Y[0], X[0], q);
+    Y[0] = *reinterpret_cast<const f32x16*>(bias_h);
+    Z = *reinterpret_cast<const f32x16*>(bias_h + 32);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const bool make = kb + 1 < 8;
+        if (make) op.begin(kb + 1, Y[kb + 1]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int s = (ob * NKB + kb) * 2 + s2;
-                const bool hand = (s + 1) % kXChunkSteps == 0;
-                const u32x4 w0 = st.w[0], w1 = st.w[1], w2 = st.w[2];
-                if (hand) xr_acquire(st, lane);
-                xr_read(st, (s + 1) % kXChunkSteps);
-                const u32x4* x = kb < NPRE ? pre[kb][s2] : (kb < NPRE + NHID ? X[kb - NPRE][s2] : post[kb - NPRE - NHID][s2]);
-                // small terms first; all six accumulate into the same block (a dependent chain issues at full rate)
-                Y[ob] = NRF_MFMA_X3(w2, x[0], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 0); __builtin_amdgcn_sched_barrier(0); }
-                Y[ob] = NRF_MFMA_X3(w0, x[2], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 1); __builtin_amdgcn_sched_barrier(0); }
-                Y[ob] = NRF_MFMA_X3(w1, x[1], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 2); __builtin_amdgcn_sched_barrier(0); }
-                Y[ob] = NRF_MFMA_X3(w1, x[0], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 3); __builtin_amdgcn_sched_barrier(0); }
-                Y[ob] = NRF_MFMA_X3(w0, x[1], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 4); __builtin_amdgcn_sched_barrier(0); }
-                Y[ob] = NRF_MFMA_X3(w0, x[0], Y[ob]);
-                if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 5); xr_advance(st); __builtin_amdgcn_sched_barrier(0); }
+                const u32x4* x = kb < 8 ? X[kb][s2] : post[kb - 8][s2];
+                const int g = b * 2 + s2;                       // which of the k-block's four steps
+                auto hook = [&](int m) {                        // 24 MFMAs, slices after MFMA 1, 4, 7, ..., 22
+                    const int n = g * 6 + m;
+                    if (make && n % 3 == 1) op.pair(Y[kb + 1], X[kb + 1], n / 3);
+                };
+                x3_step(st, lane, kb * 4 + g, b == 0 ? Y[0] : Z, x, hook);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
+    }
+    Y[1] = Z;
+#pragma unroll
+    for (int ob = 2; ob < NOB; ++ob) {
+        Y[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                x3_step(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], kb < 8 ? X[kb][s2] : post[kb - 8][s2], none);
     }
 }
 
@@ -267,20 +328,20 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
         split_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[0]);
 
         u32x4 X[8][2][3];
-        f32x16 Y[8];
-        OpSplit op_none;
-        OpReluSplit op_relu;
-        x3_layer<8, 2, 0, 0, INIT_BIAS>(st, lane, bias_h, pe, X, nullptr, Y, op_none);             // pts_linears.0
-        for (int li = 1; li <= 7; ++li) {                                                           // pts 1..7
-            x3_layer<8, 0, 8, 0, INIT_BIAS>(st, lane, bias_h + li * 256, nullptr, X, nullptr, Y, op_relu);
-            if (li == 5)  // skip: cat([pe, h]) (network.py:58) = the hidden part above + this PE pass on top
-                x3_layer<8, 2, 0, 0, INIT_ACCUM>(st, lane, nullptr, pe, X, nullptr, Y, op_none);
+        f32x16 Y[8], Z;
+        OpIn op{kActRelu, false, cst + (kOffAlphaW - kOffBias) + h * 16, 0.f};
+        // pts_linears.0 .. 7 and feature_linear (li = 8) as ONE hidden-layer body in a run-time loop; the encoding-only
+        // layer runs before li = 1 (pts_linears.0) and before li = 6 (the PE columns of the skip layer pts_linears.5,
+        // network.py:58 cat([pe, h]), accumulated onto its hidden part)
+        for (int li = 1; li <= 8; ++li) {
+            if (li == 1 || li == 6) x3_pe_layer(st, lane, bias_h, li == 6, pe, Y);
+            op.alpha = li == 8;                                       // feature_linear's input relu(h7) feeds alpha_linear
+            x3_hidden_layer<8, 0>(st, lane, bias_h + li * 256, X, nullptr, Y, Z, op);
         }
-        OpReluSplitAlpha op_alpha{cst + (kOffAlphaW - kOffBias) + h * 16, 0.f};
-        x3_layer<8, 0, 8, 0, INIT_BIAS>(st, lane, bias_h + 8 * 256, nullptr, X, nullptr, Y, op_alpha);  // feature_linear (+ alpha)
-        float sigma = op_alpha.sigma;
+        float sigma = op.sigma;
         asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
-        x3_layer<4, 0, 8, 1, INIT_BIAS>(st, lane, bias_h + 9 * 256, nullptr, X, dpe, Y, op_none);   // views_linears.0
+        OpIn op_views{kActNone, false, nullptr, 0.f};                 // feature -> views: no activation
+        x3_hidden_layer<4, 1>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, op_views);              // views_linears.0
         float r = 0.f, g = 0.f, b = 0.f;
         {
             const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
@@ -349,15 +410,15 @@ NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
         xpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
     };
-    launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0}, kXLayerStep[0]);
-    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kXLayerStep[l]);
+    launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0}, kXLayerStep[0]);
+    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kXLayerStep[l]);
     // network.py:58 cat([input_pts, h]): hidden columns 63..318 as a plain layer, then the PE columns 0..62 accumulate
-    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0}, kXLayerStep[5]);
-    launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0}, kXLayerStep[6]);
-    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kXLayerStep[7]);
-    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kXLayerStep[8]);
-    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kXLayerStep[9]);      // feature_linear
-    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256}, kXLayerStep[10]);   // views_linears.0
+    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0, 1}, kXLayerStep[5]);
+    launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0}, kXLayerStep[6]);
+    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kXLayerStep[7]);
+    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kXLayerStep[8]);
+    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kXLayerStep[9]);      // feature_linear
+    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256, 1}, kXLayerStep[10]);   // views_linears.0
     PackSmall s;
     for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
     s.bias[8] = b[8];

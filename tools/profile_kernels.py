@@ -19,7 +19,7 @@ from nerf_amd.weights import make_state_dict_arrays  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--only", default="all", choices=["all", "mlp", "composite", "sample", "bf16", "kilo", "train"])
+ap.add_argument("--only", default="all", choices=["all", "mlp", "composite", "sample", "bf16", "bf16x3", "kilo", "train"])
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -78,6 +78,14 @@ if a.only == "bf16":        # mlp_bf16_kernel, coarse + fine launch per rep
         ops.mlp_forward_rays_bf16(bf, o, d, z_f)
     torch.cuda.synchronize()
     print("done bf16")
+    sys.exit(0)
+if a.only == "bf16x3":      # mlp_bf16x3_kernel, coarse + fine launch per rep
+    xc, xf = ops.pack_state_dict_bf16x3(sd, "model", dev), ops.pack_state_dict_bf16x3(sd, "model_fine", dev)
+    for _ in range(a.reps + 1):
+        ops.mlp_forward_rays_bf16x3(xc, o, d, bins)
+        ops.mlp_forward_rays_bf16x3(xf, o, d, z_f)
+    torch.cuda.synchronize()
+    print("done bf16x3")
     sys.exit(0)
 for _ in range(a.reps):
     if a.only in ("all", "mlp"):
