@@ -16,14 +16,21 @@ split in contiguous slices over the ranks and one all_gather assembles the frame
 value = rays of the frame / max-over-ranks time per frame (strong scaling, the metric's "ms per
 800x800 frame at 1/2/4/8 MI355X"); the one-view-per-rank rate is carried as `weak_scaling`.
 
+The MLP of the default run is mlp_bf16x3_kernel: fp32 in, fp32 out, fp32 accumulate, each fp32 operand carried as
+three bf16 terms and each product as six bf16 MFMAs (every term down to 2^-24 of the product is kept).  Its distance
+to float64 is that of the fp32 kernel (1.0-1.35x on the fixtures), it holds the 1e-4 bar on every fixture and the
+full-frame spot check, and `dtype` names it; `--dtype fp32` runs the fp32 MFMA kernel, and the default line carries
+that frame as `also.fp32_frame`.
+
 The same JSON line carries
-  roofline      the dominant kernel (mlp_fwd_kernel, MFMA-bound): algorithmic FLOPs per launch
+  roofline      the dominant kernel (MFMA-bound): algorithmic FLOPs of the fp32 problem per launch
                 / its mean launch time, measured with HIP events on the launch stream inside
-                the timed region; peak = fp32 MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md)
+                the timed region; peak = bf16 MFMA 2500 / 6 TFLOP/s for bf16x3 (six MFMAs per product),
+                fp32 MFMA 157.3 TFLOP/s for --dtype fp32 (MI355X_MICROARCH.md)
   cpu_baseline  oracle/ (the CPU restatement of the reference) timed on this host's cores
                 on a bounded sample of the same rays (rank 0, N=1 only)
-  also          (N=1) BASELINE configs[4] per-view form (bf16 MLP), configs[2] (training step) and
-                configs[3] (KiloNeRF frame), measured in the same process after the headline.
+  also          (N=1) the fp32 MFMA frame, BASELINE configs[4] per-view form (bf16 MLP), configs[2] (training step)
+                and configs[3] (KiloNeRF frame), measured in the same process after the headline.
 """
 import argparse
 import json
@@ -63,9 +70,12 @@ def parse(argv=None):
                          "(strong scaling; a step = one pass over all views, a warm-up step = one view per rank; use with "
                          "--dtype bf16); frame: the ray-sharded headline of `render` alone, without per-stage events")
     ap.add_argument("--views", type=int, default=200, help="testset mode: number of views in the set")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="render mode only: fp32 = BASELINE configs[1] (the headline metric); bf16 = the bf16 MLP of "
-                         "configs[4], reported under its own metric name")
+    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "fp32", "bf16"],
+                    help="render mode only: bf16x3 (default) = BASELINE configs[1], the fp32 computation with every MLP "
+                         "operand carried as three bf16 terms on the bf16 MFMA (fp32-class: as close to float64 as the fp32 "
+                         "kernel and inside the 1e-4 bar on every fixture and the full frame, tests/test_gpu_bf16x3.py, "
+                         "tests/test_gpu_fullsize.py), `dtype` says so; fp32 = the same on the fp32 MFMA kernel; bf16 = the "
+                         "bf16 MLP of configs[4], reported under its own metric name")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -97,7 +107,7 @@ def recorded_composite_traffic():
         return None
 
 
-def cpu_baseline(seconds: float, dev=None):
+def cpu_baseline(seconds: float, dev=None, dtype="fp32"):
     """Oracle render of 1024-ray slices of the bench view until ~`seconds` of CPU time.  With `dev`, the first slices
     are then (untimed) rendered by the HIP path with the same uniforms and compared: the end-to-end flip report of
     SURVEY section 7 (fine-sample bin indices that differ because the two coarse passes differ in the last bits) and
@@ -127,25 +137,27 @@ def cpu_baseline(seconds: float, dev=None):
                       f"on torch-CPU fp32, {el:.1f} s; host has {os.cpu_count()} logical CPUs",
             "ms_per_frame_extrapolated": 1e3 * H * W * el / done}
     if kept:
-        line["parity_check"] = parity_check(sd, o, d, kept, dev)
+        line["parity_check"] = parity_check(sd, o, d, kept, dev, dtype)
     return line
 
 
-def parity_check(sd, o, d, kept, dev):
+def parity_check(sd, o, d, kept, dev, dtype="fp32"):
     """HIP path vs the oracle's kept slices (the oracle is the checker here, never the thing measured)."""
     from nerf_amd import ops
     from nerf_amd.renderer import near_far_table
     bins = torch.from_numpy(near_far_table(2.0, 6.0, N_COARSE)).to(dev)
-    pc, pf = ops.pack_state_dict(sd, "model", dev), ops.pack_state_dict(sd, "model_fine", dev)
+    pack = ops.pack_state_dict_bf16x3 if dtype == "bf16x3" else ops.pack_state_dict
+    mlp = ops.mlp_forward_rays_bf16x3 if dtype == "bf16x3" else ops.mlp_forward_rays
+    pc, pf = pack(sd, "model", dev), pack(sd, "model_fine", dev)
     flips = samples = 0
     err = {"fine_rgb_map": 0.0, "fine_depth_map": 0.0, "alpha_map": 0.0}
     for r0, u, u2, ref in kept:
         n = u.shape[0]
         ro, rd = torch.from_numpy(o[r0:r0 + n]).to(dev), torch.from_numpy(d[r0:r0 + n]).to(dev)
-        raw = ops.mlp_forward_rays(pc, ro, rd, bins)
+        raw = mlp(pc, ro, rd, bins)
         _, _, w, _ = ops.composite(raw, bins, True, True)
         z, _, idx = ops.sample_fine(w, bins, bins, torch.from_numpy(u).to(dev), torch.from_numpy(u2).to(dev), want_debug=True)
-        rgb, depth, _, acc = ops.composite(ops.mlp_forward_rays(pf, ro, rd, z), z, True, False)
+        rgb, depth, _, acc = ops.composite(mlp(pf, ro, rd, z), z, True, False)
         flips += int((idx.cpu().numpy().astype(np.int64) != ref["bin_indices"].numpy()).sum())
         samples += idx.numel()
         for k, got in (("fine_rgb_map", rgb), ("fine_depth_map", depth), ("alpha_map", acc)):
@@ -530,15 +542,16 @@ def testset_bench(args, net, dev, rank, world, dist):
         elapsed = float(t.item())
     assert torch.isfinite(out["fine_rgb_map"]).all()
     if rank == 0:
-        bf16 = args.dtype == "bf16"
+        bf16, x3 = args.dtype == "bf16", args.dtype == "bf16x3"
         flop = float(len(poses)) * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
-        peak = (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS) * world
+        peak = (BF16_MFMA_PEAK_TFLOPS if bf16 else BF16_MFMA_PEAK_TFLOPS / 6 if x3 else FP32_MFMA_PEAK_TFLOPS) * world
         achieved = flop * args.steps / elapsed / 1e12
         line = {
             "metric": "rays/sec (%d-view test set, 800x800, 64 coarse + 128 fine samples/ray%s)" % (len(poses), ", bf16 MLP" if bf16 else ""),
             "value": len(poses) * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps / len(poses),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if bf16 else "bf16x3" if x3 else "f32",
             "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
             "config": {"workload": "BASELINE configs[4]: %d-view test-set render, views dealt round-robin over %d rank(s), %s MLP"
                                    % (len(poses), world, args.dtype), "views": len(poses), "rays_per_frame": R,
@@ -565,8 +578,9 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=dtype)
-    bf16 = dtype == "bf16"
-    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    bf16, x3 = dtype == "bf16", dtype == "bf16x3"
+    # bf16x3: six bf16 MFMAs stand for one fp32 product, so the ceiling on the FLOPs of the fp32 problem is peak / 6
+    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else BF16_MFMA_PEAK_TFLOPS / 6 if x3 else FP32_MFMA_PEAK_TFLOPS
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
     R = H * W
@@ -628,7 +642,8 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
     ms_step = 1e3 * elapsed / steps
     mine = -(-R // world)                                      # rays of rank 0's slice (the largest)
     line = {
-        "metric": "rays/sec (full 800x800 frame, 64 coarse + 128 fine samples/ray)" + (", bf16 MLP" if bf16 else ""),
+        "metric": "rays/sec (full 800x800 frame, 64 coarse + 128 fine samples/ray)" +
+                  (", bf16 MLP" if bf16 else ""),
         "value": R * steps / elapsed,
         "unit": "rays/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -637,10 +652,12 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
         "higher_is_better": True,
         "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None,
-        "dtype": "bf16" if bf16 else "f32",
+        "dtype": "bf16" if bf16 else "bf16x3 (f32 operands as 3 bf16 terms, f32 accumulate; f32 elsewhere)" if x3 else "f32",
         "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
         "config": {"workload": ("BASELINE configs[4] per-view form: full 800x800 test-view render, NeRF coarse+fine, bf16 MLP "
                                 "(bf16 weights + activations, fp32 accumulate), " if bf16 else
+                                "BASELINE configs[1] with the MLP's fp32 operands carried as three bf16 terms each (six bf16 "
+                                "MFMAs per product, fp32 accumulate; fp32 in, fp32 out, fp32 everywhere else), " if x3 else
                                 "BASELINE configs[1]: full 800x800 lego test-view render, NeRF coarse+fine, fp32, ") +
                                ("one view per step on one GPU" if world == 1 else
                                 "one view per step, its rays in contiguous slices over %d ranks, outputs all-gathered on "
@@ -664,9 +681,10 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
         whole = world == 1
         line["roofline"] = {
             "kernel": "mlp_bf16_kernel (fused points + PE + 8x256 MLP, bf16 MFMA)" if bf16 else
-                      "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
+                      "mlp_bf16x3_kernel (fused points + PE + 8x256 MLP, 6 bf16 MFMAs per fp32 product; peak = bf16 peak / 6)"
+                      if x3 else "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": recorded_traffic(bf16) if whole else None,
+            "traffic": recorded_traffic(bf16) if whole and not x3 else None,
             "traffic_note": "HBM bytes per launch (mean of coarse + fine) from the committed rocprofv3 PMC passes of this "
                             "command at 1 GPU (profiles/); algorithmic bytes per launch %.4g"
                             % (0.5 * mine * ((N_COARSE + N_COARSE + N_IMPORTANCE) * 16 + 48 + (N_COARSE + N_IMPORTANCE) * 4)),
@@ -687,7 +705,7 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
                             "achieved": achieved, "peak": peak * world, "unit": "TFLOP/s", "frac": achieved / (peak * world),
                             "traffic": None}
     if cpu and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, None if bf16 else dev)
+        line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, None if bf16 else dev, dtype)
     return line
 
 
@@ -703,6 +721,9 @@ def also_block(args, net, dev):
     sub = argparse.Namespace(**vars(args))
     sub.no_cpu_baseline = True
     out = {}
+    other = "fp32" if args.dtype == "bf16x3" else "bf16x3"    # the headline's other fp32-class kernel, same view sequence
+    out[other + "_frame"] = cut(render_bench(sub, net, dev, 0, 1, None, dtype=other, steps=3, warmup=1, cpu=False))
+    torch.cuda.empty_cache()
     out["bf16_frame"] = cut(render_bench(sub, net, dev, 0, 1, None, dtype="bf16", steps=5, warmup=1, cpu=False))
     torch.cuda.empty_cache()
     sub.steps, sub.warmup = 20, 3
@@ -851,7 +872,7 @@ def run_mode(args, dev, rank, world, dist):
     if args.mode == "frame":
         return render_bench(args, net, dev, rank, world, dist, dtype=args.dtype, staged=False)
     line = render_bench(args, net, dev, rank, world, dist, dtype=args.dtype)
-    if line is not None and world == 1 and args.dtype == "fp32" and not args.no_also:
+    if line is not None and world == 1 and args.dtype != "bf16" and not args.no_also:
         line["also"] = also_block(args, net, dev)
     return line
 

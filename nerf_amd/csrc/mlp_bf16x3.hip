@@ -26,6 +26,10 @@ constexpr int kXChunkSteps = 8;
 constexpr int kXChunkBytes = kXChunkSteps * kXStepBytes;   // 24 KiB
 constexpr int kXRing = 5;
 constexpr int kXPieces = kXChunkBytes / 1024 / 4;     // LDS-DMA pieces per wave per chunk: 6
+#ifndef X3_LOOK
+#define X3_LOOK 2
+#endif
+constexpr int kXLook = X3_LOOK;                       // LDS -> register look-ahead of the weight fragments, in steps (< 4)
 constexpr int kXStepsL0 = 8 * 2 * 2;                  // 8 out blocks x 2 PE k-blocks x 2 k16-steps
 constexpr int kXStepsHidden = 8 * 8 * 2;              // 128
 constexpr int kXStepsViews = 4 * 9 * 2;               // 72
@@ -115,9 +119,13 @@ struct XRing {
     char* smem;
     int pf_slot, rd_slot;
     const u32x4* rd;     // this lane's 16 B of term 0 of step 0 of the chunk being read
-    u32x4 w[3];          // the three weight fragments of the next step to be multiplied (already read from LDS)
+    u32x4 wq[4][3];      // the three weight fragments of steps s .. s + kXLook - 1 (slot = step & 3), read from LDS
+                         // kXLook steps ahead of their MFMAs
 };
 __device__ __forceinline__ void xr_piece(const XRing& st, int j) {
+#ifdef X3_ABL_NODMA   // timing-only ablation builds (tools/debug/x3_ablate.py): results are wrong
+    return;
+#endif
     glds16(st.gnext + j * 1024, __builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kXChunkBytes + j * 1024));
 }
 __device__ __forceinline__ void xr_advance(XRing& st) {
@@ -127,14 +135,22 @@ __device__ __forceinline__ void xr_advance(XRing& st) {
     st.pf_slot = st.pf_slot + 1 == kXRing ? 0 : st.pf_slot + 1;
 }
 __device__ __forceinline__ void xr_acquire(XRing& st, int lane) {
+#ifndef X3_ABL_NOBARRIER
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(kXPieces * (kXRing - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
+#endif
     st.rd_slot = st.rd_slot + 1 == kXRing ? 0 : st.rd_slot + 1;
     st.rd = reinterpret_cast<const u32x4*>(st.smem + st.rd_slot * kXChunkBytes) + lane;
 }
-__device__ __forceinline__ void xr_read(XRing& st, int step_in_chunk) {
+__device__ __forceinline__ void xr_read1(XRing& st, int slot, int step_in_chunk, int t) {
+#ifdef X3_ABL_NOLDS     // timing-only: operands stay whatever the registers hold
+    return;
+#endif
+    st.wq[slot][t] = st.rd[(step_in_chunk * 3 + t) * 64];
+}
+__device__ __forceinline__ void xr_read(XRing& st, int slot, int step_in_chunk) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) st.w[t] = st.rd[(step_in_chunk * 3 + t) * 64];
+    for (int t = 0; t < 3; ++t) xr_read1(st, slot, step_in_chunk, t);
 }
 __device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, char* smem, int wave, int lane) {
     st.gbegin = stream_base + wave * (kXPieces * 1024) + lane * 16;
@@ -143,17 +159,20 @@ __device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, cha
     st.smem = smem;
     st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * unsigned(kXPieces * 1024));
     st.pf_slot = 0;
+    // the state of a stream in flight at step 0: chunks 0 .. kXRing-2 on their way and the last slot's refill at piece
+    // kXLook (x3_step issues piece (s + kXLook) % 8 of the current refill on step s)
 #pragma unroll
     for (int i = 0; i < kXRing; ++i) {
 #pragma unroll
-        for (int jj = 0; jj < kXPieces; ++jj) xr_piece(st, jj);
-        xr_advance(st);
+        for (int jj = 0; jj < (i + 1 < kXRing ? kXPieces : kXLook); ++jj) xr_piece(st, jj);
+        if (i + 1 < kXRing) xr_advance(st);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kXPieces * (kXRing - 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kXPieces * (kXRing - 2) + kXLook) : "memory");
     __builtin_amdgcn_s_barrier();
     st.rd_slot = 0;
     st.rd = reinterpret_cast<const u32x4*>(smem) + lane;
-    xr_read(st, 0);
+#pragma unroll
+    for (int i = 0; i < kXLook; ++i) xr_read(st, i, i);
 }
 
 #define NRF_MFMA_X3(a, b, c) \
@@ -177,7 +196,33 @@ struct OpIn {
             for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], hx[t], sigma);
         }
     }
+    // the same pair in three sub-slices of ~5 VALU instructions, one per MFMA gap (15 in one gap hold the wave's
+    // in-order MFMA issue for 60 cycles: the matrix pipe runs dry behind them)
+    float sa, sb, ra, rb;
+    unsigned p0, p1;
+    __device__ __forceinline__ void sub(const f32x16& y, u32x4 (&x)[2][3], int q, int phase) {
+#ifdef X3_ABL_NOSPLIT
+        if (phase == 0) pair(y, x, q);
+        return;
+#endif
+        if (phase == 0) {
+            const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
+            sa = __int_as_float(b0 > lim ? b0 : lim), sb = __int_as_float(b1 > lim ? b1 : lim);
+            p0 = pk_bf16(sa, sb);
+            x[q / 4][0][q % 4] = p0;
+        } else if (phase == 1) {
+            ra = __fsub_rn(sa, bf_lo(p0)), rb = __fsub_rn(sb, bf_hi(p0));
+            p1 = pk_bf16(ra, rb);
+            x[q / 4][1][q % 4] = p1;
+        } else {
+            x[q / 4][2][q % 4] = pk_bf16(__fsub_rn(ra, bf_lo(p1)), __fsub_rn(rb, bf_hi(p1)));
+        }
+    }
     __device__ __forceinline__ void pair(const f32x16& y, u32x4 (&x)[2][3], int q) {
+#ifdef X3_ABL_NOSPLIT   // timing-only: one move per output register instead of the 15-instruction split
+        x[q / 4][0][q % 4] = __float_as_uint(y[2 * q]), x[q / 4][1][q % 4] = __float_as_uint(y[2 * q + 1]), x[q / 4][2][q % 4] = 0x3c003c00u;
+        return;
+#endif
         const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
         unsigned p0, p1, p2;
         split_pair(__int_as_float(b0 > lim ? b0 : lim), __int_as_float(b1 > lim ? b1 : lim), p0, p1, p2);
@@ -186,33 +231,36 @@ struct OpIn {
 };
 
 // One k16-step of the stream: the six MFMAs of one (output block, k16) pair into `y`; `hook(m)` runs after MFMA m.
-// The ring hand-over (acquire + the wave's 6 refill pieces, one per MFMA gap) rides on a chunk's last step.
+// The ring hand-over (acquire; the wave's 6 refill pieces on this and the next five steps) rides on the step kXLook before a chunk's end.
 template <class Hook>
 __device__ __forceinline__ void x3_step(XRing& st, int lane, int s /* stream step inside the layer */, f32x16& y,
                                         const u32x4* x, Hook&& hook) {
-    const bool hand = (s + 1) % kXChunkSteps == 0;
-    const u32x4 w0 = st.w[0], w1 = st.w[1], w2 = st.w[2];
+    // the hand-over to the next chunk comes with the first read that reaches into it, kXLook steps before the chunk's end
+    // the wave's six refill pieces follow one per step (the four waves leave the barrier together: six pieces each in
+    // six consecutive gaps are 128 B/clk asked of a 64 B/clk address path, and the MFMA issue waits behind them)
+    const int piece = (s + kXLook) % kXChunkSteps;
+    const bool hand = piece == 0;
+    const u32x4 w0 = st.wq[s & 3][0], w1 = st.wq[s & 3][1], w2 = st.wq[s & 3][2];
     if (hand) xr_acquire(st, lane);
-    xr_read(st, (s + 1) % kXChunkSteps);
+    // one ds_read_b128 per MFMA gap (three in one gap saturate the LDS array when the four waves coincide)
+    const int rs = (s + kXLook) & 3, rc = (s + kXLook) % kXChunkSteps;
     // small terms first; all six accumulate into the same block (a dependent chain issues at full rate)
-    y = NRF_MFMA_X3(w2, x[0], y);
-    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 0); __builtin_amdgcn_sched_barrier(0); }
-    hook(0);
-    y = NRF_MFMA_X3(w0, x[2], y);
-    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 1); __builtin_amdgcn_sched_barrier(0); }
-    hook(1);
-    y = NRF_MFMA_X3(w1, x[1], y);
-    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 2); __builtin_amdgcn_sched_barrier(0); }
-    hook(2);
-    y = NRF_MFMA_X3(w1, x[0], y);
-    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 3); __builtin_amdgcn_sched_barrier(0); }
-    hook(3);
-    y = NRF_MFMA_X3(w0, x[1], y);
-    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 4); __builtin_amdgcn_sched_barrier(0); }
-    hook(4);
-    y = NRF_MFMA_X3(w0, x[0], y);
-    if (hand) { __builtin_amdgcn_sched_barrier(0); xr_piece(st, 5); xr_advance(st); __builtin_amdgcn_sched_barrier(0); }
-    hook(5);
+    // Every MFMA gap is its own scheduling region: left alone, the compiler (at ~420 live registers) sinks the
+    // look-ahead reads down to their first use and reorders the six MFMAs, and every step then waits out the LDS latency.
+#define X3_GAP(m, wa, xb, RD)                                                                            \
+    y = NRF_MFMA_X3(wa, xb, y);                                                                          \
+    RD;                                                                                                  \
+    if (m == 4 && piece < kXPieces) { xr_piece(st, piece); if (piece == kXPieces - 1) xr_advance(st); }  \
+    hook(m);                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
+    X3_GAP(0, w2, x[0], xr_read1(st, rs, rc, 0))
+    X3_GAP(1, w0, x[2], xr_read1(st, rs, rc, 1))
+    X3_GAP(2, w1, x[1], xr_read1(st, rs, rc, 2))
+    X3_GAP(3, w1, x[0], (void)0)
+    X3_GAP(4, w0, x[1], (void)0)
+    X3_GAP(5, w0, x[0], (void)0)
+#undef X3_GAP
 }
 
 // Encoding-only layer (pts_linears.0, and the skip layer's PE pass which ACCUMULATES onto pts_linears.5's hidden part):
@@ -259,23 +307,28 @@ __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float
             for (int s2 = 0; s2 < 2; ++s2) {
                 const u32x4* x = kb < 8 ? X[kb][s2] : post[kb - 8][s2];
                 const int g = b * 2 + s2;                       // which of the k-block's four steps
-                auto hook = [&](int m) {                        // 24 MFMAs, slices after MFMA 1, 4, 7, ..., 22
+                auto hook = [&](int m) {                        // 24 MFMAs: pair n / 3, sub-slice n % 3 after MFMA n
                     const int n = g * 6 + m;
-                    if (make && n % 3 == 1) op.pair(Y[kb + 1], X[kb + 1], n / 3);
+                    if (make) op.sub(Y[kb + 1], X[kb + 1], n / 3, n % 3);
+                    // the next block's bias is read one step ahead of its first MFMA (Y[2] is free: X[2] is made)
+                    if (kb == NKB - 1 && g == 3 && m == 0 && NOB > 2) Y[2] = *reinterpret_cast<const f32x16*>(bias_h + 2 * 32);
                 };
                 x3_step(st, lane, kb * 4 + g, b == 0 ? Y[0] : Z, x, hook);
-                __builtin_amdgcn_sched_barrier(0);
             }
     }
     Y[1] = Z;
 #pragma unroll
     for (int ob = 2; ob < NOB; ++ob) {
-        Y[ob] = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                x3_step(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], kb < 8 ? X[kb][s2] : post[kb - 8][s2], none);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                auto hook = [&](int m) {
+                    if (kb == NKB - 1 && s2 == 1 && m == 0 && ob + 1 < NOB)
+                        Y[ob + 1] = *reinterpret_cast<const f32x16*>(bias_h + (ob + 1) * 32);
+                };
+                x3_step(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], kb < 8 ? X[kb][s2] : post[kb - 8][s2], hook);
+            }
     }
 }
 
@@ -329,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
 
         u32x4 X[8][2][3];
         f32x16 Y[8], Z;
-        OpIn op{kActRelu, false, cst + (kOffAlphaW - kOffBias) + h * 16, 0.f};
+        OpIn op{kActRelu, false, cst + (kOffAlphaW - kOffBias) + h * 16, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
         // pts_linears.0 .. 7 and feature_linear (li = 8) as ONE hidden-layer body in a run-time loop; the encoding-only
         // layer runs before li = 1 (pts_linears.0) and before li = 6 (the PE columns of the skip layer pts_linears.5,
         // network.py:58 cat([pe, h]), accumulated onto its hidden part)
@@ -340,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
         }
         float sigma = op.sigma;
         asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
-        OpIn op_views{kActNone, false, nullptr, 0.f};                 // feature -> views: no activation
+        OpIn op_views{kActNone, false, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};                 // feature -> views: no activation
         x3_hidden_layer<4, 1>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, op_views);              // views_linears.0
         float r = 0.f, g = 0.f, b = 0.f;
         {

@@ -215,3 +215,71 @@ def test_bf16_full_frame_oracle_spot_check(frame_bf16):
         print(f"bf16 frame spot check {k}: vs bf16 oracle {e16:.2e}, vs fp32 oracle {e32:.2e}")
         assert e32 < tol, (k, e32)
         assert e16 < tol, (k, e16)
+
+
+# ---- bf16x3 MLP at full size: the fp32 headline's kernel (three-term bf16 operands, fp32-class) -------------------------
+@pytest.fixture(scope="module")
+def frame_x3(dev):
+    from nerf_amd import ops
+    from nerf_amd.camera import focal_from_angle, test_set_poses
+    from nerf_amd.config import default_cfg
+    from nerf_amd.network import Network
+    from nerf_amd.renderer import Renderer
+    from nerf_amd.weights import make_state_dict
+    net = Network()
+    net.load_state_dict(make_state_dict(0, 30.0, 2.0))
+    r = Renderer(net.to(dev), default_cfg(perturb=0), mlp_dtype="bf16x3")
+    o, d = ops.raygen(test_set_poses(200)[3], H, W, focal_from_angle(W), dev)      # the fp32 frame's view and uniforms
+    g = torch.Generator(device=dev).manual_seed(7)
+    u = torch.rand((H * W, 128), device=dev, generator=g)
+    u2 = torch.rand((H * W, 128), device=dev, generator=g)
+    with torch.no_grad():
+        out = r.render_rays(o, d, u, u2)
+    torch.cuda.synchronize()
+    return r, o, d, u, u2, out
+
+
+@pytest.mark.parametrize("first,count", [(0, 4096), (123457, 65536), (640000 - 1000, 1000), (320000, 31)])
+def test_x3_slices_of_the_frame_are_bit_identical(frame_x3, first, count):
+    r, o, d, u, u2, out = frame_x3
+    for k in KEYS:
+        assert out[k].shape[0] == H * W and torch.isfinite(out[k]).all(), k
+    sl = slice(first, first + count)
+    with torch.no_grad():
+        part = r.render_rays(o[sl].contiguous(), d[sl].contiguous(), u[sl].contiguous(), u2[sl].contiguous())
+    for k in KEYS:
+        assert torch.equal(part[k], out[k][sl]), k
+
+
+def test_x3_full_frame_oracle_spot_check(frame_x3):
+    """The fp32 frame's 48-ray spot check at the fp32 bar (1e-4 abs) against the fp32 oracle = the reference."""
+    from nerf_amd.weights import make_state_dict
+    from oracle import nerf_oracle as O
+    r, o, d, u, u2, out = frame_x3
+    idx = torch.linspace(0, H * W - 1, 48).long()
+    idx[:8] = torch.tensor([0, 799, 320400, 320401, 400 * 800 + 399, 639999, 200 * 800 + 400, 600 * 800 + 400])
+    sd = make_state_dict(0, 30.0, 2.0)
+    di = idx.to(o.device)
+    with torch.no_grad():
+        ref = O.render(sd, o[di].cpu().numpy(), d[di].cpu().numpy(), u=u[di].cpu().numpy(), u2=u2[di].cpu().numpy(),
+                       bins_table=r._bins.cpu().numpy())
+    for k in KEYS:
+        want = ref[k].numpy()
+        got = out[k][di].cpu().numpy().reshape(want.shape)
+        err = float(np.abs(got - want).max())
+        print(f"bf16x3 frame spot check {k}: {err:.2e}")
+        assert err < 1e-4, (k, err)
+
+
+def test_x3_frame_against_the_fp32_frame(frame, frame_x3):
+    """The two kernels on the same view and uniforms, all 640,000 rays: away from the rays whose fine samples fell in
+    another bin (last-bit differences of the coarse weights) the maps agree to the fp32 bar."""
+    out32, out3 = frame[5], frame_x3[5]
+    worst = {}
+    for k in KEYS:
+        diff = (out32[k].reshape(H * W, -1) - out3[k].reshape(H * W, -1)).abs().amax(1)
+        worst[k] = float(diff.max())
+        frac = float((diff > 1e-4).float().mean())
+        print(f"bf16x3 vs fp32 frame {k}: max {worst[k]:.2e}, rays over 1e-4: {frac:.2e}")
+        assert frac < 2e-4, (k, frac)
+    assert worst["coarse_rgb_map"] < 1e-4 and worst["coarse_depth_map"] < 1e-4     # no resampling before the coarse maps

@@ -1,45 +1,53 @@
-// Microbenchmark: v_mfma_f32_32x32x2_f32 throughput with NACC independent accumulator chains,
-// one wave per SIMD (256 threads per block, 512-register budget), every CU busy.
+// Does a chain of v_mfma_f32_32x32x16_bf16 that all accumulate into the SAME block issue at the rate of two alternating
+// chains (one wave per SIMD)?  And what does one ds_read_b128 per gap cost either of them?
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_chain.hip -o tools/ubench/mfma_chain
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NACC>
-__global__ __launch_bounds__(256, 1) void chain(float* out, int iters, float a0, float b0) {
-    f32x16 acc[NACC];
-    for (int i = 0; i < NACC; ++i)
-        for (int j = 0; j < 16; ++j) acc[i][j] = threadIdx.x * 0.001f + i;
-    float a = a0 + threadIdx.x * 1e-6f, b = b0;
-    for (int it = 0; it < iters; ++it) {
+template <int CHAINS, int LDS>
+__global__ __launch_bounds__(256, 1) void k(unsigned long long* out, float* sink) {
+    __shared__ u32x4 sm[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) sm[i] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    __syncthreads();
+    f32x16 c0 = {}, c1 = {};
+    u32x4 a = {0x3c003c00u + threadIdx.x, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    u32x4 b0 = {0x3c003c00u, 0x3c003c00u + threadIdx.x, 0x3c003c00u, 0x3c003c00u}, b1 = b0;
+    u32x4 w = a;
+    const unsigned p = unsigned(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)sm)) + (threadIdx.x & 63) * 16;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 512; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            if (CHAINS == 1)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %4, %0"
+                             : "+v"(c0), "+v"(c1) : "v"(a), "v"(b0), "v"(b1));
+            else
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
+                             : "+v"(c0), "+v"(c1) : "v"(a), "v"(b0), "v"(b1));
+            if (LDS) {
+                // the wait covers reads issued at least two MFMAs earlier
+                if (j == 3) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w) :: "memory"); b1 = w; }
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(p), "n"(0));
+            }
+        }
     }
-    float s = 0;
-    for (int i = 0; i < NACC; ++i)
-        for (int j = 0; j < 16; ++j) s += acc[i][j];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+    sink[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[3] + w[0];
 }
 
-template <int NACC>
-void run(float* d, int iters) {
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    chain<NACC><<<256, 256>>>(d, 10, 1e-3f, 1e-3f);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
-    chain<NACC><<<256, 256>>>(d, iters, 1e-3f, 1e-3f);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double n = double(iters) * 16 * NACC;           // MFMAs per wave
-    double flops = n * 4096.0 * 1024;                // 1024 waves
-    printf("NACC=%d  %.3f ms  %.1f TFLOP/s  cycles/MFMA @2.4GHz = %.2f\n", NACC, ms, flops / ms / 1e9, ms * 1e-3 * 2.4e9 / n);
+template <int CHAINS, int LDS> void run() {
+    unsigned long long* out; float* sink;
+    (void)hipMalloc(&out, 256 * 4 * 8); (void)hipMalloc(&sink, 256 * 256 * 4);
+    for (int r = 0; r < 2; ++r) k<CHAINS, LDS><<<256, 256>>>(out, sink);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[1024]; (void)hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    double s = 0; for (int i = 0; i < 1024; ++i) s += double(h[i]);
+    printf("%d chain(s), %s: %.2f ticks per MFMA\n", CHAINS, LDS ? "one ds_read_b128 per 2 MFMAs" : "no LDS", s / 1024 / 4096);
 }
-
 int main() {
-    float* d; hipMalloc(&d, 256 * 256 * 4);
-    for (int rep = 0; rep < 2; ++rep) { run<1>(d, 4000); run<2>(d, 2000); run<4>(d, 1000); }
+    run<2, 0>(); run<1, 0>(); run<2, 1>(); run<1, 1>();
     return 0;
 }
