@@ -85,12 +85,13 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def recorded_traffic(bf16: bool = False):
+def recorded_traffic(dtype: str = "fp32"):
     """HBM bytes per MLP launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE,
-    MI355X_MICROARCH.md corrections): profiles/r01_mlp_traffic_pmc.json (mlp_fwd_kernel) or
-    profiles/r02_bf16_traffic_pmc.json (mlp_bf16_kernel).  Counters cannot be read from inside the process, so this is
-    the recorded figure, or None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_bf16_traffic_pmc.json" if bf16 else "r01_mlp_traffic_pmc.json")
+    MI355X_MICROARCH.md corrections): profiles/r01_mlp_traffic_pmc.json (mlp_fwd_kernel), r02_bf16x3_traffic_pmc.json
+    (mlp_bf16x3_kernel) or r02_bf16_traffic_pmc.json (mlp_bf16_kernel); tools/run_bench_traffic.sh collects them.
+    Counters cannot be read from inside the process, so this is the recorded figure, or None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", {"fp32": "r01_mlp_traffic_pmc.json", "bf16x3": "r02_bf16x3_traffic_pmc.json",
+                                           "bf16": "r02_bf16_traffic_pmc.json"}[dtype])
     try:
         with open(path) as f:
             return float(json.load(f)["traffic_bytes_per_launch_mean"])
@@ -684,7 +685,7 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
                       "mlp_bf16x3_kernel (fused points + PE + 8x256 MLP, 6 bf16 MFMAs per fp32 product; peak = bf16 peak / 6)"
                       if x3 else "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": recorded_traffic(bf16) if whole and not x3 else None,
+            "traffic": recorded_traffic(dtype) if whole else None,
             "traffic_note": "HBM bytes per launch (mean of coarse + fine) from the committed rocprofv3 PMC passes of this "
                             "command at 1 GPU (profiles/); algorithmic bytes per launch %.4g"
                             % (0.5 * mine * ((N_COARSE + N_COARSE + N_IMPORTANCE) * 16 + 48 + (N_COARSE + N_IMPORTANCE) * 4)),
