@@ -189,6 +189,16 @@ int nrf_mse_grad(const float* x, const float* target, int64_t n, float* grad, fl
 int nrf_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float grad_scale,
                   float clip_value, float lr, float beta1, float beta2, float eps, int step, nrf_stream_t stream);
 
+/* The same with an L2 regulariser on the tail [reg_begin, n) folded into the pass, for the KiloNeRF trainer whose
+ * colour-regularised tensors (kilonerf/network.py:357-384, trainers/kilonerf.py:52-55) are the tail of its flat buffer:
+ * before scale / clip / Adam, grads[i] += 2 reg_grad_coeff params[i] (written back, as nrf_l2_reg leaves it) and, if
+ * loss_accum is non-NULL, *loss_accum += reg_loss_coeff * sum(params[i]^2) over the tail (the parameters before the
+ * update).  With several ranks reg_grad_coeff = l2_reg * world (grad_scale divides it again), reg_loss_coeff = l2_reg.
+ * All four buffers 16-byte aligned. */
+int nrf_clip_adam_l2(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float grad_scale,
+                     float clip_value, float lr, float beta1, float beta2, float eps, int step, int64_t reg_begin,
+                     float reg_grad_coeff, float reg_loss_coeff, float* loss_accum, nrf_stream_t stream);
+
 /* ---- KiloNeRF: src/models/kilonerf/network.py, src/models/kilonerf/renderer/volumn_renderer.py ---- */
 
 /* Per-cell MFMA streaming layout of the 12 batched tensors of BatchedKiloNeRF (network.py:87-113),
@@ -209,6 +219,24 @@ int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_cells);
 int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host, const float* pts,
                      const float* dirs, const int32_t* dir_index, int64_t n_points, float* raw, void* workspace,
                      int64_t workspace_bytes, nrf_stream_t stream);
+
+/* nrf_kilo_pack_weights (and, with packed_t non-NULL, nrf_kilo_pack_weights_transposed) for the cells with
+ * cell_mask[cell] != 0 only (int32 per cell, device); the other cells' records are left as they are. */
+int nrf_kilo_pack_weights_cells(const float* const* tensors_host, int num_cells, const int32_t* cell_mask, float* packed,
+                                float* packed_t, nrf_stream_t stream);
+
+/* nrf_kilo_forward for a training step, whose parameters change every step (BatchedKiloNeRF.forward reads the live
+ * nn.Parameters, kilonerf/network.py:123-167): between routing and the MLPs, the records of the cells this batch
+ * routes to are packed from the 12 tensors (`tensors_host` as in nrf_kilo_pack_weights) into `packed` and, if non-NULL,
+ * `packed_t` (nrf_kilo_pack_weights_transposed's layout, for nrf_kilo_backward) -- except cells that `packed_cells`
+ * (int32 per cell, device, or NULL) marks as packed from these parameters already (nrf_kilo_pack_weights_cells with
+ * the cells the occupancy grid can reach, launched while the host waits for the sample count).  Records of other
+ * cells are left as they were: both buffers are only good for this batch's forward and backward. */
+int nrf_kilo_forward_packing(const float* const* tensors_host, const int32_t* packed_cells, float* packed, float* packed_t,
+                             int num_cells,
+                             const float* aabb_host, const int* res_host, const float* pts, const float* dirs,
+                             const int32_t* dir_index, int64_t n_points, float* raw, void* workspace,
+                             int64_t workspace_bytes, nrf_stream_t stream);
 
 /* Occupancy-grid marching + early-ray-termination compositing: what volumn_renderer.py:78-86, 107-113 delegate
  * to nerfacc (absent, unpinned).  This library's own rule: intervals [t0 + k*step, min(t0 + (k+1)*step, t1)) over
@@ -291,6 +319,63 @@ int nrf_kilo_cells_scatter(const float* records, const int32_t* cells, int n_cel
  * l2_reg * Network.get_color_reg_loss() (kilonerf/network.py:357-384, trainers/kilonerf.py:52-55), one call per
  * tensor (view_linears_{weights,biases}, rgb_linear_{weights,biases}). */
 int nrf_l2_reg(const float* params, int64_t n, float coeff, float* grad_accum, float* loss_accum, nrf_stream_t stream);
+
+/* One KiloNeRF training forward + backward in one host call: the body of NetworkWrapper.forward
+ * (src/train/trainers/kilonerf.py:34-63: render, mse(rgb) [+ mse(alpha) when target_alpha is non-NULL, the distillation
+ * stage]) and loss.backward() (trainer.py:68-72) for one batch of rays -- nrf_kilo_march_count, the host read of the
+ * sample count, nrf_kilo_march_write, nrf_kilo_forward_packing, nrf_kilo_composite, nrf_mse_grad,
+ * nrf_kilo_composite_backward, nrf_kilo_backward, issued back to back from C; while the count travels to the host
+ * the records of the cells marked in `reach` are repacked from the parameters (nrf_kilo_pack_weights_cells).  The
+ * colour regulariser and the optimiser are nrf_clip_adam_l2, after the caller's gradient all-reduce.
+ * Returns NRF_ERR_WORKSPACE with *n_samples set when the batch has more samples than max_samples: size the workspace
+ * for that (nrf_kilo_train_workspace_bytes) and call again.  The call blocks the host once (the sample count); it
+ * keeps a pinned word and an event per device for that, created on the first call on the device.  Calls from
+ * several host threads on one device must not overlap. */
+typedef struct nrf_kilo_train_args {
+    const float* rays_o;         /* (n_rays, 3) */
+    const float* rays_d;         /* (n_rays, 3) */
+    int64_t n_rays;
+    const uint8_t* occ;          /* occupancy grid, (occ_res) C order */
+    const int* occ_res;          /* HOST {rx, ry, rz} of the occupancy grid */
+    const float* aabb;           /* HOST {min xyz, max xyz} */
+    const int* res;              /* HOST {rx, ry, rz} of the cell grid */
+    int num_cells;
+    float t_near, t_far, step, ert_eps;
+    int white_bkgd;
+    const float* target_rgb;     /* (n_rays, 3) */
+    const float* target_alpha;   /* (n_rays,) or NULL (fine-tuning stage: rgb loss only) */
+    const float* const* tensors; /* HOST array of the 12 parameter tensors (nrf_kilo_pack_weights order) */
+    float* const* grads;         /* HOST array of 12 gradient tensors, every element overwritten */
+    const int32_t* reach;        /* (num_cells,) int32 or NULL: cells to repack while the sample count travels */
+    float* packed;               /* nrf_kilo_packed_floats(num_cells) floats; good for this batch only */
+    float* packed_t;             /* nrf_kilo_packed_bwd_floats(num_cells) floats */
+    float* rgb_map;              /* out (n_rays, 3) */
+    float* depth_map;            /* out (n_rays,) */
+    float* acc_map;              /* out (n_rays,) */
+    float* loss_accum;           /* out: one float, zeroed here, then mse terms added */
+    int32_t* touched;            /* out (num_cells,) int32 or NULL: 1 where the batch has samples */
+    int32_t* live;               /* in/out (num_cells,) int32 or NULL: live[c] |= (the batch has samples in c), nrf_kilo_clip_adam's mask */
+    int64_t* n_samples;          /* HOST out: samples of this batch */
+    int64_t max_samples;
+    void* workspace;
+    int64_t workspace_bytes;
+} nrf_kilo_train_args;
+int64_t nrf_kilo_train_workspace_bytes(int64_t n_rays, int64_t max_samples, int num_cells, float t_near, float t_far,
+                                       float step);
+int nrf_kilo_train_forward_backward(const nrf_kilo_train_args* args, nrf_stream_t stream);
+
+/* nrf_clip_adam_l2 for the 12 batched KiloNeRF tensors (trainer.py:74-75 + optimizer.py:9-29 over
+ * BatchedKiloNeRF's parameters), one block per cell: params / grads / exp_avg / exp_avg_sq are HOST arrays of 12 DEVICE
+ * tensors (nrf_kilo_pack_weights order, each 16-byte aligned).  `live` (int32 per cell, or NULL = every cell): cells
+ * with live == 0 are skipped in the eight unregularised tensors -- exact, not an approximation, PROVIDED such a
+ * cell's gradient and both moments are zero in those tensors (true for a cell no batch has sampled since the optimiser
+ * state was zeroed: Adam then computes p - lr * (0 / eps) = p); the caller keeps `live` as the running OR of the
+ * cells its batches touched (nrf_kilo_train_args.touched).  The four colour-regularised tensors (the last four) get
+ * grads += 2 reg_grad_coeff p (written back) and *loss_accum += reg_loss_coeff sum p^2 in every cell; with both
+ * coefficients zero they are treated like the first eight. */
+int nrf_kilo_clip_adam(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, int num_cells,
+                       const int32_t* live, float grad_scale, float clip_value, float lr, float beta1, float beta2, float eps,
+                       int step, float reg_grad_coeff, float reg_loss_coeff, float* loss_accum, nrf_stream_t stream);
 
 /* ---- whole forward path: volume_renderer.py:143-153 (render_coarse + render_fine) --- */
 

@@ -18,7 +18,7 @@ SYMBOLS = (
     "nrf_sample_fine", "nrf_render_workspace_bytes", "nrf_render", "nrf_render_bf16",
     "nrf_packed_bwd_floats", "nrf_pack_weights_transposed", "nrf_mlp_train_tiles", "nrf_mlp_acts_bytes",
     "nrf_mlp_masks_bytes", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_model_param_floats",
-    "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mse_grad", "nrf_clip_adam",
+    "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mse_grad", "nrf_clip_adam", "nrf_clip_adam_l2", "nrf_kilo_forward_packing", "nrf_kilo_pack_weights_cells", "nrf_kilo_train_workspace_bytes", "nrf_kilo_train_forward_backward", "nrf_kilo_clip_adam",
     "nrf_kilo_packed_floats", "nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward_workspace_bytes",
     "nrf_kilo_forward", "nrf_kilo_march_workspace_bytes", "nrf_kilo_march_count", "nrf_kilo_march_write",
     "nrf_kilo_composite", "nrf_occ_bake_workspace_bytes", "nrf_occ_bake",
@@ -45,6 +45,17 @@ class RenderArgs(C.Structure):
         ("n_rays", I64), ("n_coarse", INT), ("n_importance", INT), ("white_bkgd", INT),
         ("coarse_rgb", P), ("coarse_depth", P), ("fine_rgb", P), ("fine_depth", P), ("fine_acc", P),
         ("workspace", P), ("workspace_bytes", I64),
+    ]
+
+
+class KiloTrainArgs(C.Structure):
+    """struct nrf_kilo_train_args (include/nerf_amd.h)."""
+    _fields_ = [
+        ("rays_o", P), ("rays_d", P), ("n_rays", I64), ("occ", P), ("occ_res", P), ("aabb", P), ("res", P),
+        ("num_cells", INT), ("t_near", C.c_float), ("t_far", C.c_float), ("step", C.c_float), ("ert_eps", C.c_float),
+        ("white_bkgd", INT), ("target_rgb", P), ("target_alpha", P), ("tensors", P), ("grads", P), ("reach", P),
+        ("packed", P), ("packed_t", P), ("rgb_map", P), ("depth_map", P), ("acc_map", P), ("loss_accum", P),
+        ("touched", P), ("live", P), ("n_samples", P), ("max_samples", I64), ("workspace", P), ("workspace_bytes", I64),
     ]
 
 
@@ -108,6 +119,18 @@ def lib() -> C.CDLL:
     L.nrf_clip_adam.argtypes = [P, P, P, P, I64, F, F, F, F, F, F, INT, P]
     L.nrf_mse_grad.restype = INT
     L.nrf_clip_adam.restype = INT
+    L.nrf_clip_adam_l2.argtypes = [P, P, P, P, I64, F, F, F, F, F, F, INT, I64, F, F, P, P]
+    L.nrf_clip_adam_l2.restype = INT
+    L.nrf_kilo_forward_packing.argtypes = [P, P, P, P, INT, P, P, P, P, P, I64, P, P, I64, P]
+    L.nrf_kilo_forward_packing.restype = INT
+    L.nrf_kilo_pack_weights_cells.argtypes = [P, INT, P, P, P, P]
+    L.nrf_kilo_pack_weights_cells.restype = INT
+    L.nrf_kilo_train_workspace_bytes.argtypes = [I64, I64, INT, C.c_float, C.c_float, C.c_float]
+    L.nrf_kilo_train_workspace_bytes.restype = I64
+    L.nrf_kilo_train_forward_backward.argtypes = [C.POINTER(KiloTrainArgs), P]
+    L.nrf_kilo_train_forward_backward.restype = INT
+    L.nrf_kilo_clip_adam.argtypes = [P, P, P, P, INT, P, F, F, F, F, F, F, INT, F, F, P, P]
+    L.nrf_kilo_clip_adam.restype = INT
     L.nrf_packed_bf16_bytes.restype = I64
     L.nrf_packed_bf16_bytes.argtypes = []
     L.nrf_pack_weights_bf16.restype = INT

@@ -23,9 +23,14 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void kilo_pack_kernel(KiloSrc s, int num_cells, float* __restrict__ packed) {
+// `active` / `done` (optional, one int per cell): only cells with active != 0 and done == 0 are packed, the others'
+// records are left as they are (the training step packs the cells its batch can reach, nrf_kilo_pack_weights_cells,
+// nrf_kilo_forward_packing)
+__global__ __launch_bounds__(256) void kilo_pack_kernel(KiloSrc s, int num_cells, const int* __restrict__ active,
+                                                        const int* __restrict__ done, float* __restrict__ packed) {
     __shared__ float rec[kRecFloats];
     const int cell = blockIdx.x;
+    if ((active && active[cell] == 0) || (done && done[cell] != 0)) return;
     stage_cell_record(s, cell, rec);
     __syncthreads();
     for (int idx = threadIdx.x; idx < kKiloCellFloats; idx += 256) {
@@ -566,7 +571,23 @@ NRF_EXPORT int nrf_kilo_pack_weights(const float* const* tensors, int num_cells,
     }
     if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
     nrf_launch_begin();
-    kilo_pack_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, packed);
+    kilo_pack_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, nullptr, nullptr, packed);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_kilo_pack_weights_cells(const float* const* tensors, int num_cells, const int32_t* cell_mask, float* packed,
+                                           float* packed_t, nrf_stream_t stream) {
+    if (!tensors || !packed || !cell_mask) return NRF_ERR_NULL;
+    if (num_cells <= 0) return NRF_ERR_SHAPE;
+    KiloSrc s;
+    for (int i = 0; i < 12; ++i) {
+        if (!tensors[i]) return NRF_ERR_NULL;
+        s.t[i] = tensors[i];
+    }
+    if (!nrf_aligned16(packed) || (packed_t && !nrf_aligned16(packed_t))) return NRF_ERR_ALIGN;
+    nrf_launch_begin();
+    kilo_pack_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, cell_mask, nullptr, packed);
+    if (packed_t) kilo_pack_t_launch(s.t, num_cells, cell_mask, nullptr, packed_t, static_cast<hipStream_t>(stream));
     return nrf_launch_status();
 }
 
@@ -593,12 +614,16 @@ NRF_EXPORT int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_ce
 
 // Network.forward (kilonerf/network.py:223-311) for a flat batch: raw[i] = [r, g, b, sigma] of point i
 // evaluated by the MLP of its cell.  dirs: (n, 3), or (m, 3) with dir_index (n,) int32 into it.
-NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host,
-                                const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
-                                float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream_) {
+// `src` (optional): the 12 parameter tensors; the cells the batch routes to (and `done`, if given, does not mark as
+// packed already) are packed from them into `packed` (and `packed_t`, if given) between the routing histogram and the
+// MLP launch.
+static int kilo_forward_impl(const KiloSrc* src, const int32_t* done, float* packed_t, const float* packed, int num_cells, const float* aabb_host,
+                             const int* res_host, const float* pts, const float* dirs, const int32_t* dir_index,
+                             int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream_) {
     if (n_points < 0 || num_cells <= 0 || n_points > (1LL << 28)) return NRF_ERR_SHAPE;  // 32-bit byte offsets in the kernels
     if (n_points == 0) return NRF_OK;
     if (!packed || !aabb_host || !res_host || !pts || !dirs || !raw || !workspace) return NRF_ERR_NULL;
+    if (packed_t && !nrf_aligned16(packed_t)) return NRF_ERR_ALIGN;
     if (res_host[0] * res_host[1] * res_host[2] != num_cells || num_cells > 8192) return NRF_ERR_SHAPE;
     if (workspace_bytes < nrf_kilo_forward_workspace_bytes(n_points, num_cells)) return NRF_ERR_WORKSPACE;
     if (!nrf_aligned16(packed) || !nrf_aligned16(raw) || !nrf_aligned16(workspace)) return NRF_ERR_ALIGN;
@@ -619,6 +644,10 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
     // tiles of one cell per weight load: up to kJobTiles, fewer for small batches so that every wavefront gets jobs
     int64_t jt = (n_points + 32 * 4 * int64_t(cus) * 4 - 1) / (32 * 4 * int64_t(cus) * 4);
     const int job_tiles = int(jt < 4 ? 4 : jt > kJobTiles ? kJobTiles : jt);
+    if (src) {   // hist[cell] = samples routed to the cell: pack those cells, nobody reads the others' records
+        kilo_pack_kernel<<<dim3(unsigned(num_cells)), 256, 0, stream>>>(*src, num_cells, hist, done, const_cast<float*>(packed));
+        if (packed_t) kilo_pack_t_launch(src->t, num_cells, hist, done, packed_t, stream);
+    }
     kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, job_tiles, seg_start, cursor, job_prefix);
     kilo_scatter_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(cell, n_points, num_cells, cursor, perm);
     if (dir_index)
@@ -628,6 +657,28 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
         kilo_mlp_kernel<false><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
                                                                         dirs, dir_index, reinterpret_cast<float4*>(raw));
     return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host,
+                                const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
+                                float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream) {
+    return kilo_forward_impl(nullptr, nullptr, nullptr, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
+                             workspace, workspace_bytes, stream);
+}
+
+NRF_EXPORT int nrf_kilo_forward_packing(const float* const* tensors, const int32_t* packed_cells, float* packed, float* packed_t,
+                                        int num_cells,
+                                        const float* aabb_host, const int* res_host, const float* pts, const float* dirs,
+                                        const int32_t* dir_index, int64_t n_points, float* raw, void* workspace,
+                                        int64_t workspace_bytes, nrf_stream_t stream) {
+    if (!tensors) return NRF_ERR_NULL;
+    KiloSrc s;
+    for (int i = 0; i < 12; ++i) {
+        if (!tensors[i]) return NRF_ERR_NULL;
+        s.t[i] = tensors[i];
+    }
+    return kilo_forward_impl(&s, packed_cells, packed_t, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
+                             workspace, workspace_bytes, stream);
 }
 
 // ---- rendering ------------------------------------------------------------------------------

@@ -65,7 +65,10 @@ __global__ void kilo_job_scan_kernel(const int* __restrict__ seg_start, int ncel
             b += (seg_start[c + 1] - seg_start[c] + span - 1) / span;
         }
     }
-    if (tid == 1023) job_prefix[ncell] = s_a[1023];
+    if (tid == 1023) {
+        job_prefix[ncell] = s_a[1023];
+        job_prefix[ncell + 1] = 0;   // kilo_bwd_kernel's job counter
+    }
 }
 
 // grads[t][cell] = sum of the cell's job records, in job order
@@ -103,9 +106,11 @@ __global__ __launch_bounds__(256) void kilo_grad_reduce_kernel(const float* __re
 
 // A operands of the transposed chain: lane (row = input feature, half h), MFMA t contracts over output feature
 // acc_row(t, h) -- the order in which the accumulator layout presents dY^T as the B operand.
-__global__ __launch_bounds__(256) void kilo_pack_t_kernel(KiloSrc s, int num_cells, float* __restrict__ packed_t) {
+__global__ __launch_bounds__(256) void kilo_pack_t_kernel(KiloSrc s, int num_cells, const int* __restrict__ active,
+                                                          const int* __restrict__ done, float* __restrict__ packed_t) {
     __shared__ float rec[kRecFloats];
     const int cell = blockIdx.x;
+    if ((active && active[cell] == 0) || (done && done[cell] != 0)) return;   // see kilo_pack_kernel
     stage_cell_record<false>(s, cell, rec);
     __syncthreads();
     for (int idx = threadIdx.x; idx < kKiloCellTFloats; idx += 256) {
@@ -182,21 +187,27 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                                                           const int* __restrict__ job_prefix, int tiles_per_job,
                                                           const int* __restrict__ perm, const float* __restrict__ pts,
                                                           const float* __restrict__ dirs, const int* __restrict__ dir_index,
-                                                          const float4* __restrict__ grad_raw, float* __restrict__ partial) {
+                                                          const float4* __restrict__ grad_raw, float* __restrict__ partial,
+                                                          int* __restrict__ job_counter) {
     // dynamic LDS: [4 waves][tile] then [4 waves][the job's cell record: forward operands, biases, head rows]
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     float* T = s_dyn + (threadIdx.x >> 6) * (kTileRows * kTileStride);
     float* Wl = s_dyn + 4 * (kTileRows * kTileStride) + (threadIdx.x >> 6) * kKiloCellFloats;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * 4;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // encoding slot behind LDS row (32 * blk + j): the (t, h) with acc_row(t, h) == j
     const int slot_h = (j >> 2) & 1, slot_t = (j & 3) + 4 * (j >> 3);
 
+    // Jobs are 1..tiles_per_job tiles long and a wave sees only three or four of them: dealt round-robin, the waves
+    // with the long ones finish well after the rest.  Each wave takes the next job off a counter instead (the records
+    // are indexed by job, so the result does not depend on who ran what).
     const int total_jobs = job_prefix[ncell];
-    for (int job = wave_global; job < total_jobs; job += n_waves) {
+    for (;;) {
+        // (no branch around the atomic: every lane adds, lane 0 adds 1 and the others 0 -- one atomic per wave after the
+        // compiler's wave reduction, and the control flow stays uniform)
+        const int job = __builtin_amdgcn_readfirstlane(atomicAdd(job_counter, lane == 0 ? 1 : 0));
+        if (job >= total_jobs) break;
         int lo = 0, hi = ncell;                      // cell of this job: last c with job_prefix[c] <= job
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -531,6 +542,15 @@ __global__ __launch_bounds__(256) void kilo_cells_copy_kernel(KiloSrc s, const i
 
 }  // namespace
 
+// for nrf_kilo_forward_packing (kilo.hip): the transposed records of the cells with active[cell] != 0
+void kilo_pack_t_launch(const float* const* tensors, int num_cells, const int* active, const int* done, float* packed_t,
+                        hipStream_t stream) {
+    KiloSrc s;
+    for (int i = 0; i < 12; ++i) s.t[i] = tensors[i];
+    kilo_pack_t_kernel<<<dim3(unsigned(num_cells)), 256, 0, stream>>>(s, num_cells, active, done, packed_t);
+}
+
+
 NRF_EXPORT int64_t nrf_kilo_record_floats(void) { return kRecFloats; }
 
 static int cells_copy(bool gather, const float* const* tensors, const int32_t* cells, int n_cells, int num_cells,
@@ -576,7 +596,7 @@ NRF_EXPORT int nrf_kilo_pack_weights_transposed(const float* const* tensors, int
     }
     if (!nrf_aligned16(packed_t)) return NRF_ERR_ALIGN;
     nrf_launch_begin();
-    kilo_pack_t_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, packed_t);
+    kilo_pack_t_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, nullptr, nullptr, packed_t);
     return nrf_launch_status();
 }
 
@@ -589,12 +609,13 @@ static int bwd_tiles_per_job(int64_t n_points) {
     return int(t < 4 ? 4 : t);
 }
 
-// workspace of nrf_kilo_backward: job_prefix (ncell + 1) | job records
+// workspace of nrf_kilo_backward: job_prefix (ncell + 1), the job counter | job records
+static int64_t bwd_prefix_bytes(int num_cells) { return a256((int64_t(num_cells) + 2) * 4); }
 NRF_EXPORT int64_t nrf_kilo_backward_workspace_bytes(int64_t n_points, int num_cells) {
     if (n_points < 0 || num_cells <= 0) return NRF_ERR_SHAPE;
     const int64_t span = 32 * int64_t(bwd_tiles_per_job(n_points));
     const int64_t max_jobs = n_points / span + (n_points < num_cells ? n_points : num_cells);
-    return a256((int64_t(num_cells) + 1) * 4) + a256(max_jobs * kRecStride * 4);
+    return bwd_prefix_bytes(num_cells) + a256(max_jobs * kRecStride * 4);
 }
 
 // Gradients of all 12 parameter tensors for the batch nrf_kilo_forward just evaluated: `forward_workspace` is that
@@ -620,7 +641,7 @@ NRF_EXPORT int nrf_kilo_backward(const float* packed, const float* packed_t, int
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const KiloSortWs ws = kilo_sort_ws(const_cast<void*>(forward_workspace), n_points, num_cells);
     int* job_prefix = static_cast<int*>(workspace);
-    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + a256((int64_t(num_cells) + 1) * 4));
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + bwd_prefix_bytes(num_cells));
     const int tpj = bwd_tiles_per_job(n_points);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -634,17 +655,19 @@ NRF_EXPORT int nrf_kilo_backward(const float* packed, const float* packed_t, int
                             kBwdLds) != hipSuccess)
         return NRF_ERR_LAUNCH;
     if (n_points == 0) {  // no forward ran: every segment is empty
-        (void)hipMemsetAsync(job_prefix, 0, size_t(num_cells + 1) * 4, stream);
+        (void)hipMemsetAsync(job_prefix, 0, size_t(num_cells + 2) * 4, stream);
     } else {
         kilo_job_scan_kernel<<<1, 1024, 0, stream>>>(ws.seg_start, num_cells, tpj, job_prefix);
         if (dir_index)
             kilo_bwd_kernel<true><<<dim3(unsigned(cus)), 256, kBwdLds, stream>>>(packed, packed_t, num_cells, ws.seg_start, job_prefix,
                                                                            tpj, ws.perm, pts, dirs, dir_index,
-                                                                           reinterpret_cast<const float4*>(grad_raw), partial);
+                                                                           reinterpret_cast<const float4*>(grad_raw), partial,
+                                                                           job_prefix + num_cells + 1);
         else
             kilo_bwd_kernel<false><<<dim3(unsigned(cus)), 256, kBwdLds, stream>>>(packed, packed_t, num_cells, ws.seg_start, job_prefix,
                                                                             tpj, ws.perm, pts, dirs, dir_index,
-                                                                            reinterpret_cast<const float4*>(grad_raw), partial);
+                                                                            reinterpret_cast<const float4*>(grad_raw), partial,
+                                                                           job_prefix + num_cells + 1);
     }
     kilo_grad_reduce_kernel<<<dim3(unsigned(num_cells)), 256, 0, stream>>>(partial, job_prefix, g);
     return nrf_launch_status();

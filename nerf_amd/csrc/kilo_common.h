@@ -122,3 +122,9 @@ __device__ __forceinline__ PackedChunk packed_chunk(float4 rv, float delta, bool
 __device__ __forceinline__ float wave_total(float v) { return nrf_read_lane63(nrf_wave_scan_add(v)); }
 
 }  // namespace
+
+// kilo_bwd.hip, for nrf_kilo_forward_packing / nrf_kilo_pack_weights_cells (kilo.hip): the transposed records of the
+// cells with active[cell] != 0 and done[cell] == 0 (either may be NULL) from the 12 parameter tensors (host array of
+// device pointers)
+void kilo_pack_t_launch(const float* const* tensors, int num_cells, const int* active, const int* done, float* packed_t,
+                        hipStream_t stream);

@@ -291,7 +291,6 @@ __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float
                                                 const u32x4 (*post)[2][3], f32x16* Y, f32x16& Z, OpIn& op) {
     constexpr int NKB = 8 + NPOST;
     static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
-    auto none = [](int) {};
     op.begin(0, Y[0]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) op.pair(Y[0], X[0], q);

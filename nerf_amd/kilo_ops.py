@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import NrfError, check, lib
+from ._lib import KiloTrainArgs, NrfError, check, lib
 from .ops import _f32, _ptr, _stream
 from .weights import KILO_TENSORS
 
@@ -63,10 +63,57 @@ def kilo_route(pts: torch.Tensor, aabb, res) -> torch.Tensor:
     return cell
 
 
+class ParamPointers:
+    """The 12 batched tensors as the host array of device pointers the C ABI takes, built once for tensors whose
+    storage does not move (KiloTrainStep's views of its flat buffer): a training step hands it to kilo_forward /
+    kilo_pack_weights_cells without re-checking twelve tensors per call."""
+
+    def __init__(self, tensors):
+        ts = [_f32(t.detach(), "kilo tensor") for t in tensors]
+        if len(ts) != 12:
+            raise NrfError("expected the 12 batched KiloNeRF tensors")
+        self.num_cells = int(ts[0].shape[0])
+        for t, (name, shape, _) in zip(ts, KILO_TENSORS):
+            if tuple(t.shape) != (self.num_cells,) + shape:
+                raise NrfError(f"{name}: shape {tuple(t.shape)}, want {(self.num_cells,) + shape}")
+        self.tensors = ts                                     # keeps the storage alive
+        self.array = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
+        self.device = ts[0].device
+
+
+def _param_pointers(p) -> "ParamPointers":
+    return p if isinstance(p, ParamPointers) else ParamPointers(p)
+
+
+def kilo_pack_weights_cells(params, cell_mask: torch.Tensor, packed: torch.Tensor, packed_t: torch.Tensor | None = None):
+    """Records of the cells with cell_mask != 0 (int32, one per cell) from the 12 tensors into ``packed`` (and the
+    transposed layout into ``packed_t``); other records are left alone (nrf_kilo_pack_weights_cells)."""
+    pp = _param_pointers(params)
+    if cell_mask.dtype != torch.int32 or cell_mask.numel() != pp.num_cells or not cell_mask.is_cuda or not cell_mask.is_contiguous():
+        raise NrfError("cell_mask: expected a contiguous int32 cuda tensor with one entry per cell")
+    if packed.numel() != kilo_packed_floats(pp.num_cells) or (packed_t is not None and
+                                                              packed_t.numel() != kilo_packed_bwd_floats(pp.num_cells)):
+        raise NrfError("packed / packed_t: wrong size for this grid")
+    with torch.cuda.device(pp.device):
+        check(lib().nrf_kilo_pack_weights_cells(pp.array, pp.num_cells, _ptr(cell_mask), _ptr(packed), _ptr(packed_t),
+                                                _stream(packed)), "nrf_kilo_pack_weights_cells")
+
+
+def kilo_packed_floats(num_cells: int) -> int:
+    return int(lib().nrf_kilo_packed_floats(num_cells))
+
+
+def kilo_packed_bwd_floats(num_cells: int) -> int:
+    return int(lib().nrf_kilo_packed_bwd_floats(num_cells))
+
+
 def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, workspace=None,
-                 return_workspace: bool = False):
+                 return_workspace: bool = False, pack_from=None, packed_t=None, packed_cells=None):
     """raw (n, 4) = [r, g, b, sigma] per point; dirs (n, 3) or (m, 3) with int32 dir_index (n,).
-    ``return_workspace``: also return the workspace (the points' order by cell), which kilo_backward needs."""
+    ``return_workspace``: also return the workspace (the points' order by cell), which kilo_backward needs.
+    ``pack_from``: the 12 parameter tensors (or a ParamPointers); the cells this batch routes to are packed from them
+    into ``packed`` (and ``packed_t``) on the way (nrf_kilo_forward_packing), except those ``packed_cells`` (int32 per
+    cell) marks as packed already -- both buffers are then good for this batch only."""
     pts, dirs = _f32(pts, "pts").reshape(-1, 3), _f32(dirs, "dirs").reshape(-1, 3)
     n = pts.shape[0]
     if dir_index is None:
@@ -82,8 +129,23 @@ def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, w
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=pts.device)
     with torch.cuda.device(pts.device):
-        check(lib().nrf_kilo_forward(_ptr(packed), num_cells, pa, pr, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,
-                                     _ptr(raw), _ptr(workspace), workspace.numel(), _stream(pts)), "nrf_kilo_forward")
+        if pack_from is not None:
+            pp = _param_pointers(pack_from)
+            if pp.num_cells != num_cells:
+                raise NrfError("pack_from: expected the 12 batched KiloNeRF tensors of this grid")
+            if packed.numel() != kilo_packed_floats(num_cells) or (
+                    packed_t is not None and packed_t.numel() != kilo_packed_bwd_floats(num_cells)):
+                raise NrfError("packed / packed_t: wrong size for this grid")
+            if packed_cells is not None and (packed_cells.dtype != torch.int32 or packed_cells.numel() != num_cells or
+                                             not packed_cells.is_cuda or not packed_cells.is_contiguous()):
+                raise NrfError("packed_cells: expected a contiguous int32 cuda tensor with one entry per cell")
+            check(lib().nrf_kilo_forward_packing(pp.array, _ptr(packed_cells), _ptr(packed), _ptr(packed_t), num_cells, pa, pr,
+                                                 _ptr(pts), _ptr(dirs),
+                                                 _ptr(dir_index), n, _ptr(raw), _ptr(workspace), workspace.numel(),
+                                                 _stream(pts)), "nrf_kilo_forward_packing")
+        else:
+            check(lib().nrf_kilo_forward(_ptr(packed), num_cells, pa, pr, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,
+                                         _ptr(raw), _ptr(workspace), workspace.numel(), _stream(pts)), "nrf_kilo_forward")
     return (raw, workspace) if return_workspace else raw
 
 
@@ -204,11 +266,16 @@ def kilo_cells_scatter(records: torch.Tensor, cells: torch.Tensor, tensors) -> N
               "nrf_kilo_cells_scatter")
 
 
+_pinned_total = {}
+
+
 def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: float, step: float,
-               reuse_masks: bool = True):
+               reuse_masks: bool = True, after_count=None):
     """Occupancy-grid marching.  Returns (pts (N,3), ray_idx (N,), t_start (N,), t_end (N,),
     offsets (R,), counts (R,)); one host sync to learn N between the count and the write pass.  ``reuse_masks``:
-    the write pass takes the kept steps from the count pass's ballots instead of walking the grid again (same bits)."""
+    the write pass takes the kept steps from the count pass's ballots instead of walking the grid again (same bits).
+    ``after_count``: called once the count pass and the read-back of N are enqueued and before the host waits for
+    them -- GPU work that does not depend on N goes here and runs while the host wakes up and sizes the buffers."""
     rays_o, rays_d = _f32(rays_o, "rays_o").reshape(-1, 3), _f32(rays_d, "rays_d").reshape(-1, 3)
     if occ.dtype != torch.uint8 or occ.ndim != 3 or not occ.is_cuda:
         raise NrfError("occ: expected a 3-D uint8 cuda tensor")
@@ -231,7 +298,18 @@ def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: fl
         check(lib().nrf_kilo_march_count(_ptr(rays_o), _ptr(rays_d), R, _ptr(occ), pr, pa, float(t_near), float(t_far),
                                          float(step), _ptr(counts), _ptr(offsets), _ptr(total), _ptr(ws), ws.numel(),
                                          _stream(rays_o)), "nrf_kilo_march_count")
-        n = int(total.item())
+        if after_count is None:
+            n = int(total.item())
+        else:
+            host = _pinned_total.get(dev)
+            if host is None:
+                host = _pinned_total[dev] = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            host.copy_(total, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            after_count()
+            done.synchronize()
+            n = int(host[0])
         if n > MAX_POINTS:
             raise TooManySamples(n, R)
         pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -283,3 +361,91 @@ def occ_bake(packed_teacher: torch.Tensor, aabb, res, threshold: float, chunk_ce
             check(bake_fn(_ptr(packed_teacher), pa, pr, float(threshold), first, m, _ptr(occ), _ptr(ws), ws.numel(),
                           _stream(occ)), "nrf_occ_bake")
     return occ.view(int(r[0]), int(r[1]), int(r[2])).bool()
+
+
+class KiloTrainCall:
+    """nrf_kilo_train_forward_backward with its buffers kept between steps: the workspace (grown when a batch has
+    more samples than it was sized for), the per-ray outputs, and the argument block.  ``params`` / ``grads``: the 12
+    parameter tensors and their gradient tensors (storage must not move, e.g. views of flat buffers)."""
+
+    NRF_ERR_WORKSPACE = -4
+
+    def __init__(self, params, grads, packed, packed_t, loss):
+        self.pp, self.gp = ParamPointers(params), ParamPointers(grads)
+        self.packed, self.packed_t, self.loss = packed, packed_t, loss
+        self.ws = None
+        self.max_samples = 0
+        self._rays = None
+        self._n = (C.c_int64 * 1)()
+        self.args = KiloTrainArgs()
+
+    def _size(self, n_rays, need, near, far, step, dev):
+        self.max_samples = max(int(need * 1.25), 1 << 16)
+        b = int(lib().nrf_kilo_train_workspace_bytes(n_rays, self.max_samples, self.pp.num_cells, near, far, step))
+        if b < 0:
+            check(b, "nrf_kilo_train_workspace_bytes")
+        self.ws = torch.empty(b, dtype=torch.uint8, device=dev)
+
+    def __call__(self, rays_o, rays_d, occ, aabb, res, near, far, step, ert, white_bkgd, target_rgb, target_alpha, reach,
+                 touched=None, live=None):
+        """Returns (rgb, depth, acc, n_samples); grads and loss are filled; ``touched`` (int32 per cell) is set to 1
+        where the batch has samples, ``live`` gets those cells OR-ed in."""
+        o, d = _f32(rays_o, "rays_o").reshape(-1, 3), _f32(rays_d, "rays_d").reshape(-1, 3)
+        R, dev = o.shape[0], o.device
+        if occ.dtype != torch.uint8 or occ.ndim != 3 or not occ.is_cuda or not occ.is_contiguous():
+            raise NrfError("occ: expected a contiguous 3-D uint8 cuda tensor")
+        t_rgb = _f32(target_rgb, "target_rgb").reshape(-1)
+        t_alpha = None if target_alpha is None else _f32(target_alpha, "target_alpha").reshape(-1)
+        if R == 0 or t_rgb.numel() != 3 * R or (t_alpha is not None and t_alpha.numel() != R):
+            raise NrfError("KiloTrainCall: need at least one ray and one target per ray")
+        for m in (reach, touched, live):
+            if m is not None and (m.dtype != torch.int32 or m.numel() != self.pp.num_cells or not m.is_cuda):
+                raise NrfError("reach / touched: expected int32 cuda tensors with one entry per cell")
+        _a, _r, pa, pr = _grid_args(aabb, res)
+        _o, _s, _po, pocc = _grid_args(aabb, occ.shape)
+        near, far, step = float(near), float(far), float(step)
+        if self.ws is None or self._rays != R:
+            self._rays = R
+            self._size(R, self.max_samples, near, far, step, dev)
+        rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((R,), dtype=torch.float32, device=dev)
+        acc = torch.empty((R,), dtype=torch.float32, device=dev)
+        a = self.args
+        a.rays_o, a.rays_d, a.n_rays = o.data_ptr(), d.data_ptr(), R
+        a.occ, a.occ_res, a.aabb, a.res = occ.data_ptr(), pocc, pa, pr
+        a.num_cells = self.pp.num_cells
+        a.t_near, a.t_far, a.step, a.ert_eps, a.white_bkgd = near, far, step, float(ert), int(bool(white_bkgd))
+        a.target_rgb, a.target_alpha = t_rgb.data_ptr(), _ptr(t_alpha)
+        a.tensors, a.grads = C.cast(self.pp.array, C.c_void_p), C.cast(self.gp.array, C.c_void_p)
+        a.reach, a.packed, a.packed_t = _ptr(reach), self.packed.data_ptr(), self.packed_t.data_ptr()
+        a.rgb_map, a.depth_map, a.acc_map, a.loss_accum = rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(), self.loss.data_ptr()
+        a.touched, a.live, a.n_samples = _ptr(touched), _ptr(live), C.cast(self._n, C.c_void_p)
+        with torch.cuda.device(dev):
+            stream = _stream(o)
+            for _attempt in range(2):
+                a.max_samples, a.workspace, a.workspace_bytes = self.max_samples, self.ws.data_ptr(), self.ws.numel()
+                rc = lib().nrf_kilo_train_forward_backward(C.byref(a), stream)
+                if rc != self.NRF_ERR_WORKSPACE:
+                    break
+                n = int(self._n[0])
+                if n > MAX_POINTS:
+                    raise TooManySamples(n, R)
+                self._size(R, n, near, far, step, dev)        # this batch has more samples than any before: grow, again
+            check(rc, "nrf_kilo_train_forward_backward")
+        return rgb, depth, acc, int(self._n[0])
+
+
+def kilo_clip_adam(params, grads, exp_avg, exp_avg_sq, step: int, live=None, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8,
+                   clip_value=40.0, grad_scale=1.0, reg_grad_coeff=0.0, reg_loss_coeff=0.0, loss_accum=None) -> None:
+    """clip_grad_value_ + Adam over the 12 batched tensors, one block per cell (nrf_kilo_clip_adam).  Each of the four
+    arguments: the 12 tensors or a ParamPointers.  ``live`` (int32 per cell): cells that have had a gradient since the
+    moments were zeroed; the others are skipped in the unregularised tensors (their update is the identity)."""
+    pp, gp, mp, vp = (_param_pointers(x) for x in (params, grads, exp_avg, exp_avg_sq))
+    if live is not None and (live.dtype != torch.int32 or live.numel() != pp.num_cells or not live.is_cuda or
+                             not live.is_contiguous()):
+        raise NrfError("live: expected a contiguous int32 cuda tensor with one entry per cell")
+    with torch.cuda.device(pp.device):
+        check(lib().nrf_kilo_clip_adam(pp.array, gp.array, mp.array, vp.array, pp.num_cells, _ptr(live), float(grad_scale),
+                                       float(clip_value), float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                       float(reg_grad_coeff), float(reg_loss_coeff), _ptr(loss_accum), _stream(pp.tensors[0])),
+              "nrf_kilo_clip_adam")

@@ -59,6 +59,8 @@ class KiloTrainStep:
         self.reset_optimizer(lr)
         self._packed = None
         self._packed_t = None
+        self._call = None                                     # kilo_ops.KiloTrainCall, built on the first batch
+        self._reach, self._reach_key = None, None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.num_samples = 0
         self.touched = None          # (cells,) int32 mask of the cells the last deferred-regulariser batch sampled
@@ -71,11 +73,34 @@ class KiloTrainStep:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.t = 0
+        # cells that have had a gradient since the moments were zeroed: everywhere else the eight unregularised
+        # tensors have g = m = v = 0 and Adam's update is the identity, so the optimiser pass skips them
+        self.live = torch.zeros(self.params[0].shape[0], dtype=torch.int32, device=self.device)
+        views = lambda flat: [flat[g.storage_offset():g.storage_offset() + g.numel()].view(g.shape) for g in self.grads]  # noqa: E731
+        self._adam_ptrs = tuple(kilo_ops.ParamPointers(x) for x in (self.params, self.grads, views(self.exp_avg),
+                                                                    views(self.exp_avg_sq)))
 
-    def forward_backward(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation", defer_reg=False):
+    def _reachable_cells(self, occ, res):
+        """int32 mask over the cells: 1 where some occupancy voxel inside the cell is set.  A hint, not a contract (the
+        forward packs any cell the batch routes to that this mask misses); all ones when the occupancy grid is not a
+        whole multiple of the cell grid.  Recomputed when the grid tensor changes (estimator updates)."""
+        key = (occ.data_ptr(), occ._version, tuple(occ.shape), tuple(res))
+        if key != self._reach_key:
+            shape, res = list(occ.shape), [int(v) for v in res]
+            if all(s % c == 0 for s, c in zip(shape, res)):
+                f = [s // c for s, c in zip(shape, res)]
+                m = occ.reshape(res[0], f[0], res[1], f[1], res[2], f[2]).amax(dim=(1, 3, 5))
+                self._reach = (m != 0).to(torch.int32).reshape(-1).contiguous()      # flat index (x * ry + y) * rz + z
+            else:
+                self._reach = torch.ones(res[0] * res[1] * res[2], dtype=torch.int32, device=occ.device)
+            self._reach_key = key
+        return self._reach
+
+    def forward_backward(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation", defer_reg=False,
+                         want_touched=None):
         """Fills self.grad (all 12 tensors, flat) and self.loss; returns the render outputs.  ``defer_reg``: leave
-        the colour regulariser out (``step`` adds it after a compact gradient exchange) and record in
-        ``self.touched`` which cells this batch sampled."""
+        the colour regulariser out (``step`` folds it into the optimiser pass); ``want_touched`` (default: same as
+        ``defer_reg``): record in ``self.touched`` which cells this batch sampled (the compact gradient exchange)."""
         if stage not in ("distillation", "fine-tuning"):
             raise ValueError(f"stage {stage!r}: expected 'distillation' or 'fine-tuning' (train_kilonerf.py:74-78)")
         if stage == "distillation" and target_alpha is None:
@@ -87,49 +112,54 @@ class KiloTrainStep:
         aabb, res = net.grid()
         if r.occ_grid.device != o.device:
             r.occ_grid = r.occ_grid.to(o.device)
-        # march first: its count pass ends in the step's one host sync (the sample count), and the repack of all
-        # 4096 cells (0.09 ms of GPU time, no dependence on the samples) then runs while the host enqueues the rest
-        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, r.occ_grid, aabb, r.near, r.far, r.step)
-        self._packed = kilo_ops.kilo_pack_weights(self.params, out=self._packed)
-        self._packed_t = kilo_ops.kilo_pack_weights_transposed(self.params, out=self._packed_t)
-        self.num_samples = r.last_num_samples = int(pts.shape[0])
-        raw, ws = kilo_ops.kilo_forward(self._packed, net.num_models, aabb, res, pts, d, ray_idx, return_workspace=True)
-        rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, r.ert, r.white_bkgd)
-        self.loss.zero_()
-        g_rgb = ops.mse_grad(rgb, target_rgb.reshape(-1, 3), self.loss)
-        g_acc = None
+        # The parameters changed in the last step, so the kernels' records are repacked from the live tensors -- only
+        # for the cells this batch can reach.  Samples exist only in occupied voxels: the cells that hold one
+        # (`_reachable_cells`, about a third of the grid for a scene inside its occupancy grid) are packed while the
+        # host waits for the march's sample count; the forward then packs whatever else the batch routes to (normally
+        # nothing) before its MLPs.  Nobody reads the other cells' records.  The whole chain -- march, forward,
+        # compositing, losses, backward -- is ONE C call (nrf_kilo_train_forward_backward): thirty launches at 2-3 us
+        # each instead of Python's 10-20 us, which the 5-15 us kernels of this step cannot hide.
+        if self._call is None:
+            self._packed = torch.empty(kilo_ops.kilo_packed_floats(net.num_models), dtype=torch.float32, device=o.device)
+            self._packed_t = torch.empty(kilo_ops.kilo_packed_bwd_floats(net.num_models), dtype=torch.float32, device=o.device)
+            self._call = kilo_ops.KiloTrainCall(self.params, self.grads, self._packed, self._packed_t, self.loss)
         distill = stage == "distillation"
-        if distill:
-            g_acc = ops.mse_grad(acc, target_alpha.reshape(-1), self.loss)
-        g_raw = kilo_ops.kilo_composite_backward(raw, ts, te, offsets, counts, r.ert, r.white_bkgd, g_rgb, None, g_acc)
-        kilo_ops.kilo_backward(self._packed, self._packed_t, net.num_models, pts, d, ray_idx, g_raw, ws, grads=self.grads)
+        touched = None
+        if defer_reg if want_touched is None else want_touched:
+            if self.touched is None:
+                self.touched = torch.empty(net.num_models, dtype=torch.int32, device=o.device)
+            touched = self.touched
+        rgb, depth, acc, self.num_samples = self._call(
+            o, d, r.occ_grid, aabb, res, r.near, r.far, r.step, r.ert, r.white_bkgd, target_rgb,
+            target_alpha if distill else None, self._reachable_cells(r.occ_grid, res), touched,
+            self.live if self.world == 1 else None)
+        r.last_num_samples = self.num_samples
         self._reg_pending = bool(distill and self.l2_reg > 0)
-        if defer_reg:
-            self.touched = torch.zeros(net.num_models, dtype=torch.int32, device=o.device)
-            if pts.shape[0]:
-                self.touched.index_fill_(0, kilo_ops.kilo_route(pts, aabb, res).long(), 1)
-        elif self._reg_pending:   # the four regularised tensors are the tail of the flat buffer: one launch
+        if not defer_reg and self._reg_pending:   # the four regularised tensors are the tail of the flat buffer: one launch
             kilo_ops.l2_reg(self.flat[self._reg_begin:], self.l2_reg, self.grad[self._reg_begin:], self.loss)
             self._reg_pending = False
         return {"rgb_map": rgb, "depth_map": depth, "alpha_map": acc}
 
     def step(self, rays_o, rays_d, target_rgb, target_alpha=None, stage="distillation"):
         sparse = self.world > 1 and self.sparse_allreduce
-        out = self.forward_backward(rays_o, rays_d, target_rgb, target_alpha, stage, defer_reg=sparse)
+        out = self.forward_backward(rays_o, rays_d, target_rgb, target_alpha, stage, defer_reg=True, want_touched=sparse)
+        live = self.live
         if sparse:
-            # DDP semantics (mean gradient) with a compact exchange: only cells some rank sampled travel.  The
-            # regulariser is the same on every rank and non-zero everywhere, so it is added afterwards, times
-            # world (the optimiser kernel divides the sum by world); its loss term is this rank's own.
+            # DDP semantics (mean gradient) with a compact exchange: only cells some rank sampled travel
             scale = allreduce_cell_gradients(self.grads, self.touched, self.group)
-            if self._reg_pending:
-                tail = self.flat[self._reg_begin:]
-                kilo_ops.l2_reg(tail, self.l2_reg * self.world, self.grad[self._reg_begin:], None)
-                kilo_ops.l2_reg(tail, self.l2_reg, None, self.loss)
-                self._reg_pending = False
+            self.live.bitwise_or_(self.touched)                  # (now the union over the ranks)
         else:
             scale = allreduce_gradients(self.grad, self.group)   # ONE flat sum all-reduce, mean in the kernel
+            if self.world > 1:
+                live = None                                      # which cells the other ranks sampled is not known here
         self.t += 1
-        ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.t, lr=self.lr, clip_value=self.clip,
-                      grad_scale=scale)
+        # The regulariser is the same on every rank and non-zero everywhere: it rides in the optimiser pass, which reads
+        # the parameters anyway -- times world on the summed gradient (the kernel divides the sum by world), its loss
+        # term this rank's own.  self.grad ends as nrf_l2_reg would have left it.
+        reg = self._reg_pending
+        self._reg_pending = False
+        kilo_ops.kilo_clip_adam(*self._adam_ptrs, self.t, live=live, lr=self.lr, clip_value=self.clip, grad_scale=scale,
+                                reg_grad_coeff=self.l2_reg * self.world if reg else 0.0,
+                                reg_loss_coeff=self.l2_reg if reg else 0.0, loss_accum=self.loss)
         self.view.invalidate()        # the in-place update does not bump tensor versions: drop the inference pack
         return out

@@ -325,10 +325,19 @@ def mse_grad(x: torch.Tensor, target: torch.Tensor, loss_accum: torch.Tensor | N
 
 
 def clip_adam(params, grads, exp_avg, exp_avg_sq, step: int, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8,
-              clip_value=40.0, grad_scale=1.0) -> None:
-    """In-place on flat fp32 buffers (trainer.py:74-75 + optimizer.py:9-29 defaults)."""
+              clip_value=40.0, grad_scale=1.0, reg_begin=None, reg_grad_coeff=0.0, reg_loss_coeff=0.0, loss_accum=None) -> None:
+    """In-place on flat fp32 buffers (trainer.py:74-75 + optimizer.py:9-29 defaults).  ``reg_begin``: fold an L2
+    regulariser on params[reg_begin:] into the pass (nrf_clip_adam_l2: grads[reg_begin:] += 2 reg_grad_coeff p, written
+    back; loss_accum += reg_loss_coeff sum p^2)."""
     for t in (params, grads, exp_avg, exp_avg_sq):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == params.numel()
+    if reg_begin is not None:
+        with torch.cuda.device(params.device):
+            check(lib().nrf_clip_adam_l2(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(),
+                                         float(grad_scale), float(clip_value), float(lr), float(beta1), float(beta2),
+                                         float(eps), int(step), int(reg_begin), float(reg_grad_coeff), float(reg_loss_coeff),
+                                         _ptr(loss_accum), _stream(params)), "nrf_clip_adam_l2")
+        return
     with torch.cuda.device(params.device):
         check(lib().nrf_clip_adam(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(),
                                   float(grad_scale), float(clip_value), float(lr), float(beta1), float(beta2), float(eps),

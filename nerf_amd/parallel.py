@@ -61,7 +61,8 @@ def allreduce_cell_gradients(grads, touched: torch.Tensor, group=None) -> float:
     exchange moves over xGMI (a quarter for the sphere scene of the bench).  Cells no rank touched keep their local
     zeros, which is also their sum.  Returns 1 / world for the optimiser kernel, like ``allreduce_gradients``.
     Terms that are identical on every rank and not zero outside the touched cells (the colour regulariser) must be
-    added AFTER this call, scaled by world (``KiloTrainStep.step`` does)."""
+    added AFTER this call, scaled by world (``KiloTrainStep.step`` does).  On return ``touched`` holds the UNION over
+    the ranks (0 / 1): the cells whose gradient may be non-zero now."""
     import torch.distributed as dist
     from . import kilo_ops
     if not (dist.is_available() and dist.is_initialized()):
@@ -71,6 +72,7 @@ def allreduce_cell_gradients(grads, touched: torch.Tensor, group=None) -> float:
         return 1.0
     union = (touched != 0).to(torch.int32)
     _all_reduce(union, dist.ReduceOp.MAX, group)
+    touched.copy_(union)
     cells = union.nonzero().flatten().to(torch.int32)                # one host sync: the record count
     if cells.numel():
         rec = kilo_ops.kilo_cells_gather(grads, cells)

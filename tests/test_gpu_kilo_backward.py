@@ -331,3 +331,158 @@ def test_l2_reg_sizes_and_alignments(dev, n, offset):
     loss.zero_()
     kilo_ops.l2_reg(p, 1e-3, None, loss)                       # loss only
     assert abs(float(loss) - want_l) <= 1e-5 * max(1.0, want_l)
+
+
+def test_forward_packing_equals_pack_then_forward(dev):
+    """nrf_kilo_forward_packing: same bits out as nrf_kilo_pack_weights + nrf_kilo_forward; the cells the batch
+    routes to carry the full pack's records (forward and transposed layout), every other record is left alone."""
+    from nerf_amd import kilo_ops
+    sd = _sd(11, 10.0, 0.5)
+    ts = _tensors(sd, dev)
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-0.6, 0.3, size=(20000, 3)).astype(np.float32)      # part of the grid only
+    dirs = rng.normal(size=(20000, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    full, full_t = kilo_ops.kilo_pack_weights(ts), kilo_ops.kilo_pack_weights_transposed(ts)
+    want = kilo_ops.kilo_forward(full, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev))
+    lazy = torch.full_like(full, -77.0)
+    lazy_t = torch.full_like(full_t, -77.0)
+    got, ws = kilo_ops.kilo_forward(lazy, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev), return_workspace=True,
+                                    pack_from=ts, packed_t=lazy_t)
+    assert torch.equal(got, want)
+    cells = kilo_ops.kilo_route(_t(pts, dev), AABB, RES).long().unique()
+    assert 50 < cells.numel() < 2000
+    active = torch.zeros(4096, dtype=torch.bool, device=dev)
+    active[cells] = True
+    for a, b in ((lazy, full), (lazy_t, full_t)):
+        a, b = a.view(4096, -1), b.view(4096, -1)
+        assert torch.equal(a[active], b[active])
+        assert bool((a[~active] == -77.0).all())
+    # the two-stage form of the training step: a mask's cells packed ahead (nrf_kilo_pack_weights_cells), the forward
+    # packs only what the batch routes to beyond them -- a mask that misses half of the routed cells must not matter
+    ahead = torch.zeros(4096, dtype=torch.int32, device=dev)
+    ahead[cells[::2]] = 1
+    ahead[torch.tensor([0, 4095, 2048], device=dev)] = 1                    # cells the batch does not route to
+    two, two_t = torch.full_like(full, -77.0), torch.full_like(full_t, -77.0)
+    kilo_ops.kilo_pack_weights_cells(ts, ahead, two, two_t)
+    marked = ahead.bool()
+    for a, b in ((two, full), (two_t, full_t)):
+        a, b = a.view(4096, -1), b.view(4096, -1)
+        assert torch.equal(a[marked], b[marked]) and bool((a[~marked] == -77.0).all())
+    two.view(4096, -1)[cells[::2]] += 0.0                                   # (records of marked cells stay as packed ahead)
+    got2 = kilo_ops.kilo_forward(two, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev), pack_from=kilo_ops.ParamPointers(ts),
+                                 packed_t=two_t, packed_cells=ahead)
+    assert torch.equal(got2, want)
+    both = active | marked
+    for a, b in ((two, full), (two_t, full_t)):
+        a, b = a.view(4096, -1), b.view(4096, -1)
+        assert torch.equal(a[both], b[both]) and bool((a[~both] == -77.0).all())
+    # and the backward takes the lazily packed pair
+    g_raw = _t(rng.normal(size=(20000, 4)).astype(np.float32), dev)
+    # (same workspace for both: the order of a cell's points in it comes from atomics and sets the summation order)
+    want_g = kilo_ops.kilo_backward(full, full_t, 4096, _t(pts, dev), _t(dirs, dev), None, g_raw, ws)
+    got_g = kilo_ops.kilo_backward(lazy, lazy_t, 4096, _t(pts, dev), _t(dirs, dev), None, g_raw, ws)
+    for a, b in zip(got_g, want_g):
+        assert torch.equal(a, b)
+
+
+def test_reachable_cells_cover_every_routed_sample(dev):
+    """KiloTrainStep's pack-ahead mask (cells holding an occupied voxel) against the cells the marched samples are
+    routed to, on the sphere grid and on a thin-shell grid: the mask is a superset (if it ever were not, the forward
+    would pack the rest -- previous test)."""
+    from nerf_amd import kilo_ops
+    from nerf_amd.kilo_train import KiloTrainStep
+    sd, net, r, occ = _net_and_renderer(dev)
+    step = KiloTrainStep(r, dev)
+    o, d = _rays(24)
+    aabb, res = r.view.grid()
+    c = (np.arange(256) + 0.5) / 256 * 2 - 1
+    x, y, z = np.meshgrid(c, c, c, indexing="ij")
+    rad = np.sqrt(x * x + y * y + z * z)
+    for grid in (occ, ((rad > 0.5) & (rad < 0.53)).astype(np.uint8)):
+        g = _t(grid, dev)
+        reach = step._reachable_cells(g, res)
+        assert 0 < int(reach.sum()) < 4096
+        pts = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), g, aabb, 2.0, 6.0, 0.005)[0]
+        assert pts.shape[0] > 1000
+        routed = kilo_ops.kilo_route(pts, aabb, res).long().unique()
+        assert bool(reach[routed].all())
+
+
+@pytest.mark.parametrize("n,reg_begin", [(8, 8), (1027, 5), (100003, 60001), (1 << 20, 1 << 19), (4099, 0)])
+def test_clip_adam_l2_equals_l2_reg_then_clip_adam(dev, n, reg_begin):
+    """nrf_clip_adam_l2 = nrf_l2_reg on the tail (grad and loss) followed by nrf_clip_adam, bit for bit on parameters,
+    moments and the grad words; three steps so the moments are non-trivial."""
+    from nerf_amd import kilo_ops, ops
+    g = torch.Generator(device=dev).manual_seed(n)
+    p0 = torch.randn(n, device=dev, generator=g)
+    a = [p0.clone(), None, torch.zeros(n, device=dev), torch.zeros(n, device=dev)]
+    b = [p0.clone(), None, torch.zeros(n, device=dev), torch.zeros(n, device=dev)]
+    la, lb = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    for step in (1, 2, 3):
+        grad = torch.randn(n, device=dev, generator=g) * 30          # some beyond the clip value of 40
+        a[1], b[1] = grad.clone(), grad.clone()
+        la.zero_(), lb.zero_()
+        if reg_begin < n:
+            # the reference order on 2 ranks: grad += 2 (l2 * world) p on the summed gradient, loss += l2 sum p^2
+            tail_p, tail_g = a[0][reg_begin:], a[1][reg_begin:]       # unaligned views take nrf_l2_reg's scalar kernel
+            kilo_ops.l2_reg(tail_p, 2e-3, tail_g, None)
+            kilo_ops.l2_reg(tail_p, 1e-3, None, la)
+        ops.clip_adam(a[0], a[1], a[2], a[3], step, lr=1e-2, clip_value=40.0, grad_scale=0.5)
+        ops.clip_adam(b[0], b[1], b[2], b[3], step, lr=1e-2, clip_value=40.0, grad_scale=0.5, reg_begin=reg_begin,
+                      reg_grad_coeff=2e-3, reg_loss_coeff=1e-3, loss_accum=lb)
+        for x, y, name in zip(a, b, ("params", "grads", "exp_avg", "exp_avg_sq")):
+            assert torch.equal(x, y), (name, step)
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, float(la))
+
+
+def test_kilo_clip_adam_equals_flat_adam_and_skips_exactly(dev):
+    """nrf_kilo_clip_adam (one block per cell, dead cells skipped) against nrf_clip_adam_l2 over the flat buffer, bit
+    for bit on parameters, moments and gradient words, over three steps in which the set of sampled cells grows; the
+    skipped cells are exactly those where flat Adam computes the identity."""
+    from nerf_amd import kilo_ops, ops
+    from nerf_amd.weights import KILO_TENSORS
+    cells = 64
+    sizes = [cells * int(np.prod(shape)) for _, shape, _ in KILO_TENSORS]
+    n, reg_begin = sum(sizes), sum(sizes[:-4])
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def views(flat):
+        out, off = [], 0
+        for (_, shape, _), sz in zip(KILO_TENSORS, sizes):
+            out.append(flat[off:off + sz].view((cells,) + tuple(shape)))
+            off += sz
+        return out
+
+    p0 = torch.randn(n, device=dev, generator=g)
+    A = [p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)]
+    B = [p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)]
+    ptrs = [kilo_ops.ParamPointers(views(x)) for x in B]
+    la, lb = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    live = torch.zeros(cells, dtype=torch.int32, device=dev)
+    for step, touched in ((1, [3, 17]), (2, [17, 40, 63]), (3, [0])):
+        grad = torch.zeros(n, device=dev)
+        gv = views(grad)
+        for c in touched:                                  # data gradients only in the sampled cells, all 12 tensors
+            for t in gv:
+                t[c] = torch.randn(t[c].shape, device=dev, generator=g) * 30
+        live[torch.tensor(touched, device=dev)] = 1
+        A[1].copy_(grad), B[1].copy_(grad)
+        la.zero_(), lb.zero_()
+        ops.clip_adam(A[0], A[1], A[2], A[3], step, lr=1e-2, clip_value=40.0, grad_scale=0.5, reg_begin=reg_begin,
+                      reg_grad_coeff=2e-3, reg_loss_coeff=1e-3, loss_accum=la)
+        kilo_ops.kilo_clip_adam(*ptrs, step, live=live, lr=1e-2, clip_value=40.0, grad_scale=0.5, reg_grad_coeff=2e-3,
+                                reg_loss_coeff=1e-3, loss_accum=lb)
+        for x, y, name in zip(A, B, ("params", "grads", "exp_avg", "exp_avg_sq")):
+            assert torch.equal(x, y), (name, step)
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, float(la))
+    dead = live == 0
+    assert int(dead.sum()) == cells - 5
+    for t0, t1 in zip(views(p0)[:8], views(B[0])[:8]):
+        assert torch.equal(t0[dead], t1[dead])             # never sampled, not regularised: untouched
+    # no regulariser (fine-tuning stage), live = None: plain Adam over all twelve tensors
+    A[1].normal_(generator=g), B[1].copy_(A[1])
+    ops.clip_adam(A[0], A[1], A[2], A[3], 4, lr=1e-2, clip_value=40.0)
+    kilo_ops.kilo_clip_adam(*ptrs, 4, live=None, lr=1e-2, clip_value=40.0)
+    for x, y in zip(A, B):
+        assert torch.equal(x, y)
