@@ -484,14 +484,19 @@ def kilo_train_bench(args, dev, rank, world, dist):
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (random pixels of orbit views, random targets, random-init cells, sphere occupancy)",
             "config": {"workload": "KiloNeRF distillation step (SURVEY 8f rank 3), %d-ray batch per rank, 4096 cells, "
-                                   "dense Adam over 25.4 M parameters, data-parallel RCCL all-reduce of the sampled cells' "
-                                   "gradient records" % R,
+                                   "Adam over 25.4 M parameters (cells without gradient history skipped: their update is "
+                                   "the identity), data-parallel RCCL all-reduce of the sampled cells' gradient records" % R,
                        "rays_per_rank": R, "samples_per_step": n,
                        "cells_exchanged": (int((ts.touched != 0).sum()) if ts.touched is not None else None)},
-            "roofline": {"kernel": "clip_adam_kernel over the flat parameter buffer (dominant: the step is optimiser-bound)",
-                         "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                         "note": "algorithmic bytes of the Adam pass = %.0f MB per step; see DESIGN.md section 7 for the "
-                                 "per-kernel times (rocprofv3)" % (adam_bytes / 1e6)},
+            # forward 96 + backward 240 MFMAs of 32x32x2 per 32-sample tile: 12,288 + 30,720 FLOP per
+            # sample; the step's other kernels are byte movers
+            "roofline": {"kernel": "whole step: tiny-MLP FLOPs (kilo_mlp_kernel 96 + kilo_bwd_kernel 240 MFMAs per 32-sample "
+                                   "tile) / wall time; kilo_bwd_kernel is a third of the step (DESIGN 7.1, profiles/)",
+                         "bound": "mfma", "achieved": n * (12288 + 30720) / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": n * (12288 + 30720) / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None,
+                         "note": "a latency- and byte-bound step, not an MFMA-bound one: dense Adam would move %.0f MB per "
+                                 "step; see DESIGN.md section 7.1 for the per-kernel times (rocprofv3)" % (adam_bytes / 1e6)},
             "final_loss": loss}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = kilo_train_cpu_baseline(args.cpu_seconds, sd)
