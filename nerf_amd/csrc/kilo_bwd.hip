@@ -40,7 +40,7 @@ static_assert(kRecFloats == 6212, "per-cell parameter count");
 
 // single block: exclusive prefix of ceil(count / (32 * tiles_per_job)) over the cells
 __global__ void kilo_job_scan_kernel(const int* __restrict__ seg_start, int ncell, int tiles_per_job,
-                                     int* __restrict__ job_prefix) {
+                                     int* __restrict__ job_prefix, int* __restrict__ job_cell) {
     __shared__ int s_a[1024];
     const int tid = threadIdx.x;
     const int per = (ncell + 1023) / 1024, span = 32 * tiles_per_job;
@@ -62,7 +62,9 @@ __global__ void kilo_job_scan_kernel(const int* __restrict__ seg_start, int ncel
         const int c = tid * per + k;
         if (c < ncell) {
             job_prefix[c] = b;
-            b += (seg_start[c + 1] - seg_start[c] + span - 1) / span;
+            const int nj = (seg_start[c + 1] - seg_start[c] + span - 1) / span;
+            for (int q = 0; q < nj; ++q) job_cell[b + q] = c;   // the backward kernel's job -> cell table
+            b += nj;
         }
     }
     if (tid == 1023) {
@@ -174,11 +176,29 @@ __device__ __forceinline__ f32x16 tiny_layer_g(const float4* wp, f32x16 init, co
     return y;
 }
 
-__device__ __forceinline__ float half_sum(float v) {  // over the 32 lanes of a lane half
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+// Sum over the 32 lanes of a lane half, on DPP (no LDS round trips: the job record reduces 100 values this way):
+// Kogge-Stone inside each row of 16, then lane 15 of rows 0 / 2 into rows 1 / 3.  The total of half h is in lane
+// 32 h + 31 ONLY; callers read it there.
+__device__ __forceinline__ float half_sum_at31(float v) {
+    v += nrf_dpp<0x111>(0.f, v);
+    v += nrf_dpp<0x112>(0.f, v);
+    v += nrf_dpp<0x114>(0.f, v);
+    v += nrf_dpp<0x118>(0.f, v);
+    v += nrf_dpp<0x142, 0xa>(0.f, v);
     return v;
 }
+
+#ifdef KB_STAMP   // diagnostic builds (tools/debug/kilo_bwd_phases.py): s_memtime ticks per phase, summed over all waves
+__device__ unsigned long long g_kb_stamps[8];
+#define KB_T(i)                                                                       \
+    do {                                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                 \
+        if (lane == 0) atomicAdd(&g_kb_stamps[i], now_ - kb_last);                    \
+        kb_last = now_;                                                               \
+    } while (0)
+#else
+#define KB_T(i) do {} while (0)
+#endif
 
 template <bool INDEXED>
 __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restrict__ packed,
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                                                           const int* __restrict__ perm, const float* __restrict__ pts,
                                                           const float* __restrict__ dirs, const int* __restrict__ dir_index,
                                                           const float4* __restrict__ grad_raw, float* __restrict__ partial,
-                                                          int* __restrict__ job_counter) {
+                                                          int* __restrict__ job_counter, const int* __restrict__ job_cell) {
     // dynamic LDS: [4 waves][tile] then [4 waves][the job's cell record: forward operands, biases, head rows]
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63;
@@ -203,56 +223,63 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
     // with the long ones finish well after the rest.  Each wave takes the next job off a counter instead (the records
     // are indexed by job, so the result does not depend on who ran what).
     const int total_jobs = job_prefix[ncell];
+#ifdef KB_STAMP
+    unsigned long long kb_last = __builtin_amdgcn_s_memtime();
+#endif
+    // (no branch around the atomic: every lane adds, lane 0 adds 1 and the others 0 -- one atomic per wave after the
+    // compiler's wave reduction, and the control flow stays uniform.)  The next job's number is asked for at the start
+    // of the current job, so its round trip to L2 is over long before it is needed.
+    int next_job = atomicAdd(job_counter, lane == 0 ? 1 : 0);
     for (;;) {
-        // (no branch around the atomic: every lane adds, lane 0 adds 1 and the others 0 -- one atomic per wave after the
-        // compiler's wave reduction, and the control flow stays uniform)
-        const int job = __builtin_amdgcn_readfirstlane(atomicAdd(job_counter, lane == 0 ? 1 : 0));
+        // (taken in cell order: handing out the longest jobs first was measured and is slower, 0.198 vs 0.187 ms --
+        // neighbouring jobs share a cell's records in L2, and the heavy cells then all run at once)
+        const int job = __builtin_amdgcn_readfirstlane(next_job);
         if (job >= total_jobs) break;
-        int lo = 0, hi = ncell;                      // cell of this job: last c with job_prefix[c] <= job
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (job_prefix[mid] <= job) lo = mid; else hi = mid;
-        }
-        const int cell = lo;
+        next_job = atomicAdd(job_counter, lane == 0 ? 1 : 0);
+        KB_T(0);   // job fetch
+        const int cell = job_cell[job];              // (one load; the search over job_prefix was twelve dependent ones)
         const int seg_e = seg_start[cell + 1];
         const int first = seg_start[cell] + (job - job_prefix[cell]) * 32 * tiles_per_job;
         const int job_e = first + 32 * tiles_per_job < seg_e ? first + 32 * tiles_per_job : seg_e;
+        KB_T(1);   // cell search
         f32x16 dW0[2] = {zero16, zero16}, dW1 = zero16, dWf = zero16, dWv[2] = {zero16, zero16};
         f32x16 db1 = zero16, dbf = zero16, dsw = zero16, drw[3] = {zero16, zero16, zero16};
         float dsb = 0.f, drb[3] = {0.f, 0.f, 0.f};
         {
             const float* cw = packed + int64_t(cell) * kKiloCellFloats;
-            // Stage the cell's forward record in this wave's LDS slice once per job: all its loads are in flight
-            // together, and the tile loop then reads operands at LDS latency instead of L2 latency per layer.
-            {
-                wave_sync();   // the previous job's reads of this slice are done (same wave, in order)
-#pragma unroll
-                for (int g8 = 0; g8 < kKiloSteps; g8 += 8) {   // 8 float4 at a time: the register file is full of accumulators
-                    float4 stage[8];
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) stage[s] = reinterpret_cast<const float4*>(cw)[(g8 + s) * 64 + lane];
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) reinterpret_cast<float4*>(Wl)[(g8 + s) * 64 + lane] = stage[s];
-                }
-                const float4 tail0 = reinterpret_cast<const float4*>(cw)[kKiloSteps * 64 + lane];
-                const float4 tail1 = reinterpret_cast<const float4*>(cw)[kKiloSteps * 64 + 64 + (lane & 7)];
-                reinterpret_cast<float4*>(Wl)[kKiloSteps * 64 + lane] = tail0;
-                if (lane < 8) reinterpret_cast<float4*>(Wl)[kKiloSteps * 64 + 64 + lane] = tail1;
-                wave_sync();
-            }
-            const float4* w4_cell = reinterpret_cast<const float4*>(Wl) + lane;
-            const float4* wt4_cell = reinterpret_cast<const float4*>(packed_t + int64_t(cell) * kKiloCellTFloats) + lane;
-            const float* sm_cell = Wl + kKiloSteps * 256;
             const int last = job_e - 1;
             // Gather pipeline: perm -> (point, dir index, d raw) -> direction is three dependent loads; the next tile's
             // chain is issued piecewise between the phases of this tile (reads past the job's last tile are clamped to
-            // its last element: valid memory, results unused).
+            // its last element: valid memory, results unused).  The job's first chain starts here, ahead of the record
+            // staging, so its last round trip (the direction) runs under the staging's.
             auto tile_id = [&](int t) { const int k = t + j; return unsigned(perm[k < last ? k : last]); };
             unsigned id_n = tile_id(first);
             unsigned di_n = INDEXED ? unsigned(dir_index[id_n]) : id_n;
             float pn[3] = {pts[id_n * 3u], pts[id_n * 3u + 1], pts[id_n * 3u + 2]};
             float4 gr_n = grad_raw[id_n];
-            float dn[3] = {dirs[di_n * 3u], dirs[di_n * 3u + 1], dirs[di_n * 3u + 2]};
+            float dn[3];
+            KB_T(3);   // first gather chain (index, point, d raw)
+            // Stage the cell's forward record in this wave's LDS slice once per job, by LDS-DMA: 25 pieces of 1 KiB that
+            // need no registers and are all in flight together (through registers it was three dependent rounds of
+            // eight float4 -- the register file is full of accumulators -- and 18 % of the wave's time); the tile loop
+            // then reads operands at LDS latency instead of L2 latency per layer.
+            {
+                wave_sync();   // the previous job's reads of this slice are done (same wave, in order)
+                const char* src = reinterpret_cast<const char*>(cw) + lane * 16;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)Wl)));
+#pragma unroll
+                for (int s = 0; s < kKiloSteps + 1; ++s) glds16(src + s * 1024, dst + s * 1024);
+                const float4 tail1 = reinterpret_cast<const float4*>(cw)[kKiloSteps * 64 + 64 + (lane & 7)];   // last 128 B
+                dn[0] = dirs[di_n * 3u], dn[1] = dirs[di_n * 3u + 1], dn[2] = dirs[di_n * 3u + 2];
+                // the DMA pieces are invisible to the compiler's wait counting: this covers them (and the loads above)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]) : : "memory");
+                if (lane < 8) reinterpret_cast<float4*>(Wl)[kKiloSteps * 64 + 64 + lane] = tail1;
+                wave_sync();
+            }
+            KB_T(2);   // record staging
+            const float4* w4_cell = reinterpret_cast<const float4*>(Wl) + lane;
+            const float4* wt4_cell = reinterpret_cast<const float4*>(packed_t + int64_t(cell) * kKiloCellTFloats) + lane;
+            const float* sm_cell = Wl + kKiloSteps * 256;
             for (int t0 = first; t0 < job_e; t0 += 32) {
                 const bool valid = t0 + j < job_e;
                 const float px = pn[0], py = pn[1], pz = pn[2], dx = dn[0], dy = dn[1], dz = dn[2];
@@ -319,6 +346,7 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                 // next tile, stage 3
                 dn[0] = dirs[di_n * 3u], dn[1] = dirs[di_n * 3u + 1], dn[2] = dirs[di_n * 3u + 2];
 
+                KB_T(4);   // forward chain + data gradients
 #ifndef KB_ABL_NOWGRAD  // timing-only ablation builds (tools/debug/kilo_bwd_time.py): results are wrong
                 // ---- weight gradients: turn both operands through the LDS tile, one layer at a time ----
                 tile_store(T, kRowDy, d_h0, j, h);                 // layer 0: X = encoding (+ ones), rows 0..63
@@ -348,6 +376,7 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                 dWv[1] = wgrad_block(T, kRowDy, 32, dWv[1], j, h);
                 wave_sync();
 #endif
+                KB_T(5);   // weight gradients
             }
         }
 
@@ -369,9 +398,9 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
             rec[REC_OFF(8) + o * 59 + j] = dWv[0][t];
             if (colv >= 0) rec[REC_OFF(8) + o * 59 + 32 + colv] = dWv[1][t];
             if (j == 29) rec[REC_OFF(9) + o] = dWv[1][t];                    // ones column of the view layer
-            const float b1 = half_sum(db1[t]), bf = half_sum(dbf[t]), s_w = half_sum(dsw[t]);
-            const float r0 = half_sum(drw[0][t]), r1 = half_sum(drw[1][t]), r2 = half_sum(drw[2][t]);
-            if (j == 0) {
+            const float b1 = half_sum_at31(db1[t]), bf = half_sum_at31(dbf[t]), s_w = half_sum_at31(dsw[t]);
+            const float r0 = half_sum_at31(drw[0][t]), r1 = half_sum_at31(drw[1][t]), r2 = half_sum_at31(drw[2][t]);
+            if (j == 31) {
                 rec[REC_OFF(3) + o] = b1;
                 rec[REC_OFF(5) + o] = bf;
                 rec[REC_OFF(6) + o] = s_w;
@@ -380,11 +409,13 @@ __global__ __launch_bounds__(256, 1) void kilo_bwd_kernel(const float* __restric
                 rec[REC_OFF(10) + 64 + o] = r2;
             }
         }
-        const float sbs = half_sum(dsb), rb0 = half_sum(drb[0]), rb1 = half_sum(drb[1]), rb2 = half_sum(drb[2]);
-        if (lane == 0) {
+        // (both halves hold every point once: half 0's total is the sum over the tile's points)
+        const float sbs = half_sum_at31(dsb), rb0 = half_sum_at31(drb[0]), rb1 = half_sum_at31(drb[1]), rb2 = half_sum_at31(drb[2]);
+        if (lane == 31) {
             rec[REC_OFF(7)] = sbs;
             rec[REC_OFF(11)] = rb0, rec[REC_OFF(11) + 1] = rb1, rec[REC_OFF(11) + 2] = rb2;
         }
+        KB_T(6);   // the job's record
     }
 }
 
@@ -603,19 +634,20 @@ NRF_EXPORT int nrf_kilo_pack_weights_transposed(const float* const* tensors, int
 // tiles per job: 4 (128 points) unless that would make more than ~8192 + num_cells jobs
 static int bwd_tiles_per_job(int64_t n_points) {
     const int64_t t = (n_points + 32 * 8192 - 1) / (32 * 8192);
-#ifdef KB_ABL_TPJ
-    return int(t < KB_ABL_TPJ ? KB_ABL_TPJ : t);
-#endif
     return int(t < 4 ? 4 : t);
 }
 
-// workspace of nrf_kilo_backward: job_prefix (ncell + 1), the job counter | job records
+// workspace of nrf_kilo_backward: job_prefix (ncell + 1), the job counter | job records | job -> cell table.
+// The job bound assumes the shortest jobs (4 tiles), so it is monotone in n_points: a workspace sized for a sample
+// capacity (nrf_kilo_train_workspace_bytes) is large enough for every smaller batch.
 static int64_t bwd_prefix_bytes(int num_cells) { return a256((int64_t(num_cells) + 2) * 4); }
+static int64_t bwd_max_jobs(int64_t n_points, int num_cells) {
+    return n_points / (32 * 4) + (n_points < num_cells ? n_points : num_cells);
+}
 NRF_EXPORT int64_t nrf_kilo_backward_workspace_bytes(int64_t n_points, int num_cells) {
     if (n_points < 0 || num_cells <= 0) return NRF_ERR_SHAPE;
-    const int64_t span = 32 * int64_t(bwd_tiles_per_job(n_points));
-    const int64_t max_jobs = n_points / span + (n_points < num_cells ? n_points : num_cells);
-    return bwd_prefix_bytes(num_cells) + a256(max_jobs * kRecStride * 4);
+    const int64_t max_jobs = bwd_max_jobs(n_points, num_cells);
+    return bwd_prefix_bytes(num_cells) + a256(max_jobs * kRecStride * 4) + a256(max_jobs * 4);
 }
 
 // Gradients of all 12 parameter tensors for the batch nrf_kilo_forward just evaluated: `forward_workspace` is that
@@ -642,6 +674,8 @@ NRF_EXPORT int nrf_kilo_backward(const float* packed, const float* packed_t, int
     const KiloSortWs ws = kilo_sort_ws(const_cast<void*>(forward_workspace), n_points, num_cells);
     int* job_prefix = static_cast<int*>(workspace);
     float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + bwd_prefix_bytes(num_cells));
+    int* job_cell = reinterpret_cast<int*>(static_cast<char*>(workspace) + bwd_prefix_bytes(num_cells) +
+                                           a256(bwd_max_jobs(n_points, num_cells) * kRecStride * 4));
     const int tpj = bwd_tiles_per_job(n_points);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -657,17 +691,17 @@ NRF_EXPORT int nrf_kilo_backward(const float* packed, const float* packed_t, int
     if (n_points == 0) {  // no forward ran: every segment is empty
         (void)hipMemsetAsync(job_prefix, 0, size_t(num_cells + 2) * 4, stream);
     } else {
-        kilo_job_scan_kernel<<<1, 1024, 0, stream>>>(ws.seg_start, num_cells, tpj, job_prefix);
+        kilo_job_scan_kernel<<<1, 1024, 0, stream>>>(ws.seg_start, num_cells, tpj, job_prefix, job_cell);
         if (dir_index)
             kilo_bwd_kernel<true><<<dim3(unsigned(cus)), 256, kBwdLds, stream>>>(packed, packed_t, num_cells, ws.seg_start, job_prefix,
                                                                            tpj, ws.perm, pts, dirs, dir_index,
                                                                            reinterpret_cast<const float4*>(grad_raw), partial,
-                                                                           job_prefix + num_cells + 1);
+                                                                           job_prefix + num_cells + 1, job_cell);
         else
             kilo_bwd_kernel<false><<<dim3(unsigned(cus)), 256, kBwdLds, stream>>>(packed, packed_t, num_cells, ws.seg_start, job_prefix,
                                                                             tpj, ws.perm, pts, dirs, dir_index,
                                                                             reinterpret_cast<const float4*>(grad_raw), partial,
-                                                                           job_prefix + num_cells + 1);
+                                                                           job_prefix + num_cells + 1, job_cell);
     }
     kilo_grad_reduce_kernel<<<dim3(unsigned(num_cells)), 256, 0, stream>>>(partial, job_prefix, g);
     return nrf_launch_status();
@@ -704,3 +738,14 @@ NRF_EXPORT int nrf_l2_reg(const float* params, int64_t n, float coeff, float* gr
         l2_reg_kernel<false><<<dim3(grid), 256, 0, static_cast<hipStream_t>(stream)>>>(params, n, coeff, grad_accum, loss_accum);
     return nrf_launch_status();
 }
+
+#ifdef KB_STAMP
+NRF_EXPORT int nrf_debug_kb_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_kb_stamps), sizeof(g_kb_stamps)) != hipSuccess) return NRF_ERR_RUNTIME;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_kb_stamps), z, sizeof(z)) != hipSuccess) return NRF_ERR_RUNTIME;
+    }
+    return NRF_OK;
+}
+#endif
