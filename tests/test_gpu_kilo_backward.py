@@ -486,3 +486,42 @@ def test_kilo_clip_adam_equals_flat_adam_and_skips_exactly(dev):
     kilo_ops.kilo_clip_adam(*ptrs, 4, live=None, lr=1e-2, clip_value=40.0)
     for x, y in zip(A, B):
         assert torch.equal(x, y)
+
+
+def test_fused_call_grows_its_workspace_and_handles_empty_batches(dev):
+    """nrf_kilo_train_forward_backward through KiloTrainStep: (a) a sample capacity that is too small makes the call
+    return the count (NRF_ERR_WORKSPACE), the wrapper sizes the workspace for it and calls again -- same gradients as
+    with room to spare; (b) an empty occupancy grid: no samples, background image, zero data gradients, and the
+    optimiser still applies the regulariser."""
+    from nerf_amd.kilo_train import KiloTrainStep
+    from nerf_amd.kilonerf import KiloNetwork, KiloRenderer, default_kilo_cfg
+    sd, net, r, occ = _net_and_renderer(dev, seed=5)
+    o, d = _rays()
+    rng = np.random.default_rng(7)
+    t_rgb = _t(rng.uniform(size=(len(o), 3)).astype(np.float32), dev)
+    t_alpha = _t(rng.uniform(size=(len(o), 1)).astype(np.float32), dev)
+    step = KiloTrainStep(r, dev, l2_reg=0.0)
+    step.forward_backward(_t(o, dev), _t(d, dev), t_rgb, t_alpha)
+    n, want = step.num_samples, [g.clone() for g in step.grads]
+    assert n > 3000 and step._call.max_samples >= n
+    step._call.max_samples, step._call.ws = 64, None                 # force the too-small path on the next call
+    step._call._rays = None
+    step.forward_backward(_t(o, dev), _t(d, dev), t_rgb, t_alpha)
+    assert step.num_samples == n and step._call.max_samples >= n
+    for a, b in zip(step.grads, want):
+        assert torch.allclose(a, b, rtol=0, atol=1e-6 * max(1.0, float(b.abs().max())))    # (point order in a cell may differ)
+
+    net2 = KiloNetwork().to(dev)
+    r2 = KiloRenderer(net2, default_kilo_cfg(), torch.zeros((256, 256, 256), dtype=torch.uint8, device=dev))
+    step2 = KiloTrainStep(r2, dev, l2_reg=1e-3)
+    before = [p.clone() for p in step2.params]
+    out = step2.step(_t(o, dev), _t(d, dev), t_rgb, t_alpha, stage="distillation")
+    assert step2.num_samples == 0 and torch.all(out["rgb_map"] == 1) and torch.all(out["alpha_map"] == 0)
+    want_loss = float(((1 - t_rgb) ** 2).mean() + (t_alpha ** 2).mean()) + 1e-3 * sum(float((p.double() ** 2).sum()) for p in before[-4:])
+    assert abs(float(step2.loss) - want_loss) < 1e-4 * max(1.0, want_loss)
+    for i, (p0, p1, g) in enumerate(zip(before, step2.params, step2.grads)):
+        if i < 8:
+            assert torch.equal(p0, p1) and torch.all(g == 0)          # no samples, no regulariser: untouched
+        else:
+            assert torch.allclose(g, 2e-3 * p0, rtol=1e-6, atol=1e-12) and not torch.equal(p0, p1)
+    assert int(step2.live.sum()) == 0
