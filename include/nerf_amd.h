@@ -119,6 +119,11 @@ int nrf_mlp_forward_rays_bf16x3(const void* packed_x3, const float* rays_o, cons
                                 int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream);
 int nrf_mlp_forward_points_bf16x3(const void* packed_x3, const float* pts, const float* dirs, int64_t n_points,
                                   float* raw, nrf_stream_t stream);
+/* nrf_mlp_forward_rays_train on the three-term bf16 kernel: same acts / masks layout and sizes, for the fp32
+ * backward entry points (nrf_mlp_backward). */
+int nrf_mlp_forward_rays_train_bf16x3(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                                      int64_t z_stride, int64_t n_rays, int n_samples, float* raw, float* acts,
+                                      uint32_t* masks, nrf_stream_t stream);
 
 /* ---- alpha compositing: volume_renderer.py:222-224, 236-265 / 291-334 --------------- */
 

@@ -188,6 +188,26 @@ struct OpIn {
     bool alpha;        // run-time, uniform
     const float* aw;   // cst + alpha weights + h * 16
     float sigma;
+    // training forward (SAVE): the activated input of the layer goes to `save` (acts rows of this layer's input, this
+    // lane's column: mlp_fp32.hip's layout) and its relu signs to `msave` (nullptr: no activation, no mask)
+    float* save;
+    unsigned* msave;
+    unsigned mcur, mprev;
+    template <bool SAVE>
+    __device__ __forceinline__ void keep(int blk, int q, float a, float b) {
+        if (!SAVE) return;
+        const int t0 = 2 * q, t1 = 2 * q + 1;
+        save[(32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32] = a;
+        save[(32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32] = b;
+        if (msave) {
+            if (q == 0) mcur = 0u;
+            mcur |= ((a > 0.f ? 1u : 0u) << t0) | ((b > 0.f ? 1u : 0u) << t1);
+            if (q == 7) {
+                if (blk & 1) msave[(blk >> 1) * 64] = mprev | (mcur << 16);
+                else mprev = mcur;
+            }
+        }
+    }
     __device__ __forceinline__ void begin(int kb, const f32x16& y) {
         if (alpha) {
             const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
@@ -200,14 +220,12 @@ struct OpIn {
     // in-order MFMA issue for 60 cycles: the matrix pipe runs dry behind them)
     float sa, sb, ra, rb;
     unsigned p0, p1;
-    __device__ __forceinline__ void sub(const f32x16& y, u32x4 (&x)[2][3], int q, int phase) {
-#ifdef X3_ABL_NOSPLIT
-        if (phase == 0) pair(y, x, q);
-        return;
-#endif
+    template <bool SAVE>
+    __device__ __forceinline__ void sub(const f32x16& y, u32x4 (&x)[2][3], int blk, int q, int phase) {
         if (phase == 0) {
             const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
             sa = __int_as_float(b0 > lim ? b0 : lim), sb = __int_as_float(b1 > lim ? b1 : lim);
+            keep<SAVE>(blk, q, sa, sb);
             p0 = pk_bf16(sa, sb);
             x[q / 4][0][q % 4] = p0;
         } else if (phase == 1) {
@@ -218,14 +236,13 @@ struct OpIn {
             x[q / 4][2][q % 4] = pk_bf16(__fsub_rn(ra, bf_lo(p1)), __fsub_rn(rb, bf_hi(p1)));
         }
     }
-    __device__ __forceinline__ void pair(const f32x16& y, u32x4 (&x)[2][3], int q) {
-#ifdef X3_ABL_NOSPLIT   // timing-only: one move per output register instead of the 15-instruction split
-        x[q / 4][0][q % 4] = __float_as_uint(y[2 * q]), x[q / 4][1][q % 4] = __float_as_uint(y[2 * q + 1]), x[q / 4][2][q % 4] = 0x3c003c00u;
-        return;
-#endif
+    template <bool SAVE>
+    __device__ __forceinline__ void pair(const f32x16& y, u32x4 (&x)[2][3], int blk, int q) {
         const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
+        const float a = __int_as_float(b0 > lim ? b0 : lim), b = __int_as_float(b1 > lim ? b1 : lim);
+        keep<SAVE>(blk, q, a, b);
         unsigned p0, p1, p2;
-        split_pair(__int_as_float(b0 > lim ? b0 : lim), __int_as_float(b1 > lim ? b1 : lim), p0, p1, p2);
+        split_pair(a, b, p0, p1, p2);
         x[q / 4][0][q % 4] = p0, x[q / 4][1][q % 4] = p1, x[q / 4][2][q % 4] = p2;
     }
 };
@@ -286,14 +303,14 @@ __device__ __forceinline__ void x3_pe_layer(XRing& st, int lane, const float* bi
 // opens with output blocks 0 AND 1 accumulated together (stream order [kb][ob in {0,1}][s2] for that part, see
 // xpack_layer_kernel): X[kb+1] is made in eight slices under the 24 MFMAs of k-block kb.  Block 1 accumulates into the
 // spare block Z because the previous layer's Y[1] is still needed (it becomes X[1] during k-block 0).
-template <int NOB, int NPOST>
+template <int NOB, int NPOST, bool SAVE>
 __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float* bias_h, u32x4 (*X)[2][3],
                                                 const u32x4 (*post)[2][3], f32x16* Y, f32x16& Z, OpIn& op) {
     constexpr int NKB = 8 + NPOST;
     static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
     op.begin(0, Y[0]);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) op.pair(Y[0], X[0], q);
+    for (int q = 0; q < 8; ++q) op.template pair<SAVE>(Y[0], X[0], 0, q);
     Y[0] = *reinterpret_cast<const f32x16*>(bias_h);
     Z = *reinterpret_cast<const f32x16*>(bias_h + 32);
 #pragma unroll
@@ -308,7 +325,7 @@ __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float
                 const int g = b * 2 + s2;                       // which of the k-block's four steps
                 auto hook = [&](int m) {                        // 24 MFMAs: pair n / 3, sub-slice n % 3 after MFMA n
                     const int n = g * 6 + m;
-                    if (make) op.sub(Y[kb + 1], X[kb + 1], n / 3, n % 3);
+                    if (make) op.template sub<SAVE>(Y[kb + 1], X[kb + 1], kb + 1, n / 3, n % 3);
                     // the next block's bias is read one step ahead of its first MFMA (Y[2] is free: X[2] is made)
                     if (kb == NKB - 1 && g == 3 && m == 0 && NOB > 2) Y[2] = *reinterpret_cast<const f32x16*>(bias_h + 2 * 32);
                 };
@@ -332,10 +349,14 @@ __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float
 }
 
 // Persistent, one 4-wave workgroup per CU, one wave per SIMD, a wave's tile = 32 points (mlp_fp32.hip's tiling).
+// SAVE (training forward): also writes every layer's activated input and relu sign bits in mlp_fwd_kernel<true>'s
+// layout, for the fp32 backward kernels of mlp_bwd.hip.
+template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restrict__ packed, const float* __restrict__ a0,
                                                             const float* __restrict__ a1, const float* __restrict__ zbuf,
                                                             int64_t z_stride, int tiles_per_ray, int rays_mode,
-                                                            int64_t n_points, int64_t n_groups, float4* __restrict__ raw) {
+                                                            int64_t n_points, int64_t n_groups, float4* __restrict__ raw,
+                                                            float* __restrict__ acts, unsigned* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -375,31 +396,52 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
             dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
         }
         u32x4 pe[2][2][3], dpe[1][2][3];
-        split_tile(encode_block<10, 0>(px, py, pz, h), pe[0]);
-        split_tile(encode_block<10, 1>(px, py, pz, h), pe[1]);
-        split_tile(encode_block<4, 0>(dx, dy, dz, h), dpe[0]);
+        float* arow = nullptr;     // this lane's column of the tile's saved rows (mlp_fp32.hip)
+        unsigned* mrow = nullptr;
+        if (SAVE) {
+            arow = acts + tile * (int64_t(kActRows) * 32) + 4 * h * 32 + j;
+            mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+        }
+        {
+            const f32x16 e0 = encode_block<10, 0>(px, py, pz, h), e1 = encode_block<10, 1>(px, py, pz, h);
+            const f32x16 ed = encode_block<4, 0>(dx, dy, dz, h);
+            if (SAVE) {
+                store_block(arow + kActPe * 32, 0, e0);
+                store_block(arow + kActPe * 32, 1, e1);
+                store_block(arow + kActDpe * 32, 0, ed);
+            }
+            split_tile(e0, pe[0]);
+            split_tile(e1, pe[1]);
+            split_tile(ed, dpe[0]);
+        }
 
         u32x4 X[8][2][3];
         f32x16 Y[8], Z;
-        OpIn op{kActRelu, false, cst + (kOffAlphaW - kOffBias) + h * 16, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        OpIn op{kActRelu, false, cst + (kOffAlphaW - kOffBias) + h * 16, 0.f, nullptr, nullptr, 0u, 0u, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
         // pts_linears.0 .. 7 and feature_linear (li = 8) as ONE hidden-layer body in a run-time loop; the encoding-only
         // layer runs before li = 1 (pts_linears.0) and before li = 6 (the PE columns of the skip layer pts_linears.5,
         // network.py:58 cat([pe, h]), accumulated onto its hidden part)
         for (int li = 1; li <= 8; ++li) {
             if (li == 1 || li == 6) x3_pe_layer(st, lane, bias_h, li == 6, pe, Y);
             op.alpha = li == 8;                                       // feature_linear's input relu(h7) feeds alpha_linear
-            x3_hidden_layer<8, 0>(st, lane, bias_h + li * 256, X, nullptr, Y, Z, op);
+            if (SAVE) {   // the layer's input h_{li-1} = relu(Y) and its signs (mask li - 1)
+                op.save = arow + (kActH + (li - 1) * 256) * 32;
+                op.msave = mrow + (li - 1) * 4 * 64;
+            }
+            x3_hidden_layer<8, 0, SAVE>(st, lane, bias_h + li * 256, X, nullptr, Y, Z, op);
         }
         float sigma = op.sigma;
         asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
-        OpIn op_views{kActNone, false, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};                 // feature -> views: no activation
-        x3_hidden_layer<4, 1>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, op_views);              // views_linears.0
+        // feature -> views: no activation (saved as it is, no mask)
+        OpIn op_views{kActNone, false, nullptr, 0.f, SAVE ? arow + kActFeat * 32 : nullptr, nullptr, 0u, 0u, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        x3_hidden_layer<4, 1, SAVE>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, op_views);        // views_linears.0
         float r = 0.f, g = 0.f, b = 0.f;
         {
             const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
+            OpFwdSave<true> ops{SAVE ? arow + kActHv * 32 : nullptr, SAVE ? mrow + 8 * 4 * 64 : nullptr, 0u};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                const f32x16 hv = relu16(Y[kb]);
+                const f32x16 hv = SAVE ? ops(kb, Y[kb]) : relu16(Y[kb]);
                 const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
                 const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
                 const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
@@ -424,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
 }
 
 int launch_x3(const void* packed, const float* a0, const float* a1, const float* z, int64_t z_stride, int tiles_per_ray,
-              int rays_mode, int64_t n_points, float* raw, hipStream_t stream) {
+              int rays_mode, int64_t n_points, float* raw, hipStream_t stream, float* acts = nullptr, unsigned* masks = nullptr) {
     const int64_t tiles = (n_points + 31) / 32;
     const int64_t groups = (tiles + 3) / 4;
     int dev = 0, cus = 256;
@@ -432,16 +474,23 @@ int launch_x3(const void* packed, const float* a0, const float* a1, const float*
     if (cus <= 0) cus = 256;
     static bool attr_set[64] = {};
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kXLdsBytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kXLdsBytes) != hipSuccess)
             return NRF_ERR_LAUNCH;
         attr_set[dev] = true;
     }
     const unsigned grid = unsigned(groups < cus ? groups : cus);
     nrf_launch_begin();
-    mlp_bf16x3_kernel<<<dim3(grid), 256, kXLdsBytes, stream>>>(static_cast<const char*>(packed), a0, a1, z, z_stride,
-                                                               tiles_per_ray, rays_mode, n_points, groups,
-                                                               reinterpret_cast<float4*>(raw));
+    if (acts)
+        mlp_bf16x3_kernel<true><<<dim3(grid), 256, kXLdsBytes, stream>>>(static_cast<const char*>(packed), a0, a1, z, z_stride,
+                                                                         tiles_per_ray, rays_mode, n_points, groups,
+                                                                         reinterpret_cast<float4*>(raw), acts, masks);
+    else
+        mlp_bf16x3_kernel<false><<<dim3(grid), 256, kXLdsBytes, stream>>>(static_cast<const char*>(packed), a0, a1, z, z_stride,
+                                                                          tiles_per_ray, rays_mode, n_points, groups,
+                                                                          reinterpret_cast<float4*>(raw), nullptr, nullptr);
     return nrf_launch_status();
 }
 
@@ -495,6 +544,19 @@ NRF_EXPORT int nrf_mlp_forward_rays_bf16x3(const void* packed, const float* rays
     if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
     return launch_x3(packed, rays_o, rays_d, z, z_stride, n_samples / 32, 1, n_rays * n_samples, raw,
                      static_cast<hipStream_t>(stream));
+}
+
+NRF_EXPORT int nrf_mlp_forward_rays_train_bf16x3(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                                                 int64_t z_stride, int64_t n_rays, int n_samples, float* raw, float* acts,
+                                                 uint32_t* masks, nrf_stream_t stream) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (!packed || !rays_o || !rays_d || !z || !raw || !acts || !masks) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
+    return launch_x3(packed, rays_o, rays_d, z, z_stride, n_samples / 32, 1, n_rays * n_samples, raw,
+                     static_cast<hipStream_t>(stream), acts, masks);
 }
 
 NRF_EXPORT int nrf_mlp_forward_points_bf16x3(const void* packed, const float* pts, const float* dirs, int64_t n_points,

@@ -263,6 +263,24 @@ __device__ __forceinline__ unsigned sign_bits16(f32x16 v) {
     return m;
 }
 
+// relu / copy + store the activated block + collect its sign bits (training forward)
+template <bool RELU>
+struct OpFwdSave {
+    float* dst;      // acts + (tile * kActRows + first row) * 32 + 4 * h * 32 + point
+    unsigned* mdst;  // masks + ((tile * kMaskLayers + layer) * 4) * 64 + lane, or nullptr
+    unsigned cur;
+    __device__ __forceinline__ f32x16 operator()(int i, f32x16 y) {
+        const f32x16 x = RELU ? relu16(y) : y;
+        store_block(dst, i, x);
+        if (RELU) {
+            const unsigned bits = sign_bits16(x);
+            if (i & 1) mdst[(i >> 1) * 64] = cur | (bits << 16);
+            else cur = bits;
+        }
+        return x;
+    }
+};
+
 __device__ __forceinline__ f32x16 mask16(f32x16 v, unsigned bits) {
     f32x16 r;
 #pragma unroll

@@ -136,24 +136,6 @@ NRF_EXPORT int nrf_pack_weights_transposed(const float* const* w, float* packed_
 // ------------------------------------------------------------------------------------
 namespace {
 
-// relu / copy + store the activated block + collect its sign bits (training forward)
-template <bool RELU>
-struct OpFwdSave {
-    float* dst;      // acts + (tile * kActRows + first row) * 32 + 4 * h * 32 + point
-    unsigned* mdst;  // masks + ((tile * kMaskLayers + layer) * 4) * 64 + lane, or nullptr
-    unsigned cur;
-    __device__ __forceinline__ f32x16 operator()(int i, f32x16 y) {
-        const f32x16 x = RELU ? relu16(y) : y;
-        store_block(dst, i, x);
-        if (RELU) {
-            const unsigned bits = sign_bits16(x);
-            if (i & 1) mdst[(i >> 1) * 64] = cur | (bits << 16);
-            else cur = bits;
-        }
-        return x;
-    }
-};
-
 // Persistent: gridDim.x <= number of CUs, one 4-wave workgroup per CU, one wave per SIMD.
 // Tile group tg = 4 consecutive 32-point tiles, one per wave; all waves run every group (the
 // barriers of the weight ring are workgroup-wide), waves past the end just do not store.

@@ -258,8 +258,10 @@ def pack_weights_transposed(weights, out: torch.Tensor | None = None) -> torch.T
     return out
 
 
-def mlp_forward_rays_train(packed, rays_o, rays_d, z):
-    """-> (raw (R,S,4), acts, masks): the saved tensors are opaque buffers for mlp_backward."""
+def mlp_forward_rays_train(packed, rays_o, rays_d, z, kind: str = "fp32"):
+    """-> (raw (R,S,4), acts, masks): the saved tensors are opaque buffers for mlp_backward.  ``kind``: "fp32"
+    (``packed`` from pack_weights) or "bf16x3" (``packed`` from pack_weights_bf16x3: the forward on the three-term
+    bf16 kernel, same saved layout)."""
     rays_o, rays_d, z = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z, "z")
     R, S = rays_o.shape[0], z.shape[-1]
     stride = 0 if z.ndim == 1 else S
@@ -268,9 +270,14 @@ def mlp_forward_rays_train(packed, rays_o, rays_d, z):
     raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
     acts = torch.empty(max(int(L.nrf_mlp_acts_bytes(R, S)), 4) // 4, dtype=torch.float32, device=dev)
     masks = torch.empty(max(int(L.nrf_mlp_masks_bytes(R, S)), 4) // 4, dtype=torch.int32, device=dev)
+    if kind not in ("fp32", "bf16x3"):
+        raise ValueError(f"kind {kind!r}: expected 'fp32' or 'bf16x3'")
+    if S % 32 != 0:
+        raise _lib.NrfError(f"n_samples {S}: the MLP kernels take whole 32-point tiles per ray")
+    fn = L.nrf_mlp_forward_rays_train if kind == "fp32" else L.nrf_mlp_forward_rays_train_bf16x3
     with torch.cuda.device(dev):
-        check(L.nrf_mlp_forward_rays_train(_ptr(packed), _ptr(rays_o), _ptr(rays_d), _ptr(z), stride, R, S, _ptr(raw),
-                                           _ptr(acts), _ptr(masks), _stream(raw)), "nrf_mlp_forward_rays_train")
+        check(fn(_ptr(packed), _ptr(rays_o), _ptr(rays_d), _ptr(z), stride, R, S, _ptr(raw), _ptr(acts), _ptr(masks),
+                 _stream(raw)), "nrf_mlp_forward_rays_train" + ("" if kind == "fp32" else "_bf16x3"))
     return raw, acts, masks
 
 

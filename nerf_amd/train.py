@@ -30,7 +30,12 @@ def exponential_lr(base_lr: float, epoch: int, decay_epochs: int = 500, gamma: f
 
 class TrainStep:
     def __init__(self, net, device, near=2.0, far=6.0, n_coarse=64, n_importance=128, white_bkgd=True,
-                 lr=5e-4, clip_value=40.0, process_group=None):
+                 lr=5e-4, clip_value=40.0, process_group=None, forward_dtype="fp32"):
+        """``forward_dtype``: "fp32" (the fp32 MFMA kernel) or "bf16x3" -- the two forward passes on the three-term
+        bf16 kernel (fp32-class: DESIGN 3.7), which saves the same activations for the fp32 backward kernels."""
+        if forward_dtype not in ("fp32", "bf16x3"):
+            raise ValueError(f"forward_dtype {forward_dtype!r}: expected 'fp32' or 'bf16x3'")
+        self.forward_dtype = forward_dtype
         self.net = net
         self.device = torch.device(device)
         self.n_coarse, self.n_importance, self.white = n_coarse, n_importance, bool(white_bkgd)
@@ -63,6 +68,7 @@ class TrainStep:
         self.bins = torch.from_numpy(near_far_table(near, far, n_coarse)).to(self.device)
         self._packed = [None, None]
         self._packed_t = [None, None]
+        self._packed_x3 = [None, None]
         self._ws = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
@@ -70,6 +76,8 @@ class TrainStep:
         for k, (ws, bs) in enumerate(self.models):
             self._packed[k] = ops.pack_weights(ws, bs, out=self._packed[k])
             self._packed_t[k] = ops.pack_weights_transposed(ws, out=self._packed_t[k])
+            if self.forward_dtype == "bf16x3":
+                self._packed_x3[k] = ops.pack_weights_bf16x3(ws, bs, out=self._packed_x3[k])
 
     def forward_backward(self, rays_o, rays_d, gt, u, u2, u_coarse=None, u_fine=None):
         """Fills self.grad (both models, flat) and self.loss; returns the render outputs."""
@@ -78,10 +86,12 @@ class TrainStep:
         pc, pf = self._packed
         pc_t, pf_t = self._packed_t
         zc = self.bins if u_coarse is None else ops.perturb_samples(self.bins, u_coarse)
-        raw_c, acts_c, masks_c = ops.mlp_forward_rays_train(pc, rays_o, rays_d, zc)
+        x3 = self.forward_dtype == "bf16x3"
+        fc, ff = self._packed_x3 if x3 else (pc, pf)
+        raw_c, acts_c, masks_c = ops.mlp_forward_rays_train(fc, rays_o, rays_d, zc, self.forward_dtype)
         c_rgb, c_depth, w_c, _ = ops.composite(raw_c, zc, self.white, True)
         z_f = ops.sample_fine(w_c, self.bins, zc, u, u2, u_fine)
-        raw_f, acts_f, masks_f = ops.mlp_forward_rays_train(pf, rays_o, rays_d, z_f)
+        raw_f, acts_f, masks_f = ops.mlp_forward_rays_train(ff, rays_o, rays_d, z_f, self.forward_dtype)
         f_rgb, f_depth, _, f_acc = ops.composite(raw_f, z_f, self.white, False)
         self.loss.zero_()
         g_c = ops.mse_grad(c_rgb, gt, self.loss)                     # trainers/nerf.py:25-27

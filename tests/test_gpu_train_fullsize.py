@@ -62,14 +62,14 @@ def case():
     return {"dev": dev, "inp": inp, "sd0": sd0, "loss": loss, "grads": grads, "grads64": grads64, "z_fine": torch.cat(zf)}
 
 
-def _train_step(case, rays=slice(None)):
+def _train_step(case, rays=slice(None), forward_dtype="fp32"):
     from nerf_amd.network import Network
     from nerf_amd.train import TrainStep
     dev = case["dev"]
     net = Network()
     net.load_state_dict(case["sd0"])
     net.to(dev)
-    ts = TrainStep(net, dev)
+    ts = TrainStep(net, dev, forward_dtype=forward_dtype)
     i = case["inp"]
     args = [i[k][rays].to(dev).contiguous() for k in ("rays_o", "rays_d", "gt", "u", "u2", "u_coarse", "u_fine")]
     return net, ts, args
@@ -86,8 +86,10 @@ def _named_flat(ts):
     return out
 
 
-def test_gradients_of_4096_rays_match_oracle_autograd(case):
-    net, ts, args = _train_step(case)
+@pytest.mark.parametrize("forward_dtype", ["fp32", "bf16x3"])
+def test_gradients_of_4096_rays_match_oracle_autograd(case, forward_dtype):
+    """(bf16x3: the two forward passes on the three-term bf16 kernel, the backward kernels unchanged -- same bars.)"""
+    net, ts, args = _train_step(case, forward_dtype=forward_dtype)
     ts.forward_backward(*args)
     assert abs(float(ts.loss) - case["loss"]) < 1e-5, (float(ts.loss), case["loss"])
     got = _named_flat(ts)
@@ -103,7 +105,11 @@ def test_gradients_of_4096_rays_match_oracle_autograd(case):
         scale = max(float(ref.abs().max()), 1e-30)
         err = float((g - ref).abs().max())
         e_hip64, e_ref64 = float((g - g64).abs().max()), float((ref - g64).abs().max())
-        ok = err <= 2e-4 * scale or e_hip64 <= 3 * e_ref64
+        # ... or, for the bf16x3 forward, whose rounding is independent of the oracle's (the fp32 kernel's is not: same
+        # products, nearly the same order, so its error against the oracle is far below fp32 summation noise), an absolute
+        # floor: 3e-10 = 3 % of Adam's eps (1e-8), below which no update can change.  It is needed by one tensor,
+        # model_fine.alpha_linear.weight, whose 786 k-term sums cancel to 2e-7 (measured error 6.7e-11).
+        ok = err <= 2e-4 * scale or e_hip64 <= 3 * e_ref64 or (forward_dtype == "bf16x3" and e_hip64 <= 3e-10)
         rows.append((err / scale, name, scale, e_hip64 / scale, e_ref64 / scale))
         if not ok:
             bad.append(rows[-1])
@@ -180,3 +186,28 @@ def test_hip_and_oracle_fine_samples_at_4096_rays(case):
     diff = (z != ref)
     assert float(diff.float().mean()) < 1e-3, float(diff.float().mean())
     assert (z[:, 1:] >= z[:, :-1]).all()
+
+
+def test_bf16x3_training_forward_saves_what_the_fp32_forward_saves(case):
+    """nrf_mlp_forward_rays_train_bf16x3 against nrf_mlp_forward_rays_train on 512 rays x 192 samples: raw outputs and
+    every saved activation row agree to fp32 rounding (both are fp32-class evaluations of the same network), and the
+    relu sign words differ only where an activation sits within rounding of zero."""
+    from nerf_amd import ops
+    dev = case["dev"]
+    sd = case["sd0"]
+    ws = [sd[f"model_fine.{n}.weight"].to(dev) for n in ops.LAYER_NAMES]
+    bs = [sd[f"model_fine.{n}.bias"].to(dev) for n in ops.LAYER_NAMES]
+    o, d = case["inp"]["rays_o"][:512].contiguous(), case["inp"]["rays_d"][:512].contiguous()
+    z = case["z_fine"][:512].to(dev).contiguous()
+    raw32, acts32, m32 = ops.mlp_forward_rays_train(ops.pack_weights(ws, bs), o, d, z)
+    raw3, acts3, m3 = ops.mlp_forward_rays_train(ops.pack_weights_bf16x3(ws, bs), o, d, z, "bf16x3")
+    assert acts3.shape == acts32.shape and m3.shape == m32.shape
+    scale = float(raw32.abs().max())
+    assert float((raw3 - raw32).abs().max()) <= 2e-5 * max(1.0, scale)
+    assert float((acts3 - acts32).abs().max()) <= 2e-5 * max(1.0, float(acts32.abs().max()))
+    # mask words: [tile][9 layers][4 words][64 lanes]; the views layer (index 8) has 128 outputs = words 0 and 1 only
+    flips = (m3 ^ m32).view(-1, 9, 4, 64)
+    flips = torch.cat([flips[:, :8].reshape(-1), flips[:, 8, :2].reshape(-1)])
+    n_flip = int(sum(((flips >> b) & 1).sum() for b in range(32)))
+    print(f"relu sign flips: {n_flip} of {flips.numel() * 32}")
+    assert n_flip <= 1e-5 * flips.numel() * 32
