@@ -125,6 +125,15 @@ int nrf_mlp_forward_rays_train_bf16x3(const void* packed, const float* rays_o, c
                                       int64_t z_stride, int64_t n_rays, int n_samples, float* raw, float* acts,
                                       uint32_t* masks, nrf_stream_t stream);
 
+/* nrf_mlp_backward with the data-gradient chain (d h_{l-1} = W_l^T dY_l) on the three-term bf16 kernel; the weight-gradient
+ * GEMMs are the same fp32 kernels.  packed: nrf_pack_weights (head rows); packed_t_x3: nrf_pack_weights_transposed_bf16x3
+ * (nrf_packed_bwd_bf16x3_bytes() bytes).  Same workspace, acts / masks and gradient layout as nrf_mlp_backward. */
+int64_t nrf_packed_bwd_bf16x3_bytes(void);
+int nrf_pack_weights_transposed_bf16x3(const float* const* weights_host, void* packed_t_x3, nrf_stream_t stream);
+int nrf_mlp_backward_bf16x3(const float* packed, const void* packed_t_x3, const float* grad_raw, const float* acts,
+                            const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace, int64_t workspace_bytes,
+                            float* grad_flat, nrf_stream_t stream);
+
 /* ---- alpha compositing: volume_renderer.py:222-224, 236-265 / 291-334 --------------- */
 
 /* sigma = relu(raw[...,3]); rgb = sigmoid(raw[...,:3]); delta = diff(z), last = 1e10;

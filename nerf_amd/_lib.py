@@ -18,7 +18,8 @@ SYMBOLS = (
     "nrf_sample_fine", "nrf_render_workspace_bytes", "nrf_render", "nrf_render_bf16",
     "nrf_packed_bwd_floats", "nrf_pack_weights_transposed", "nrf_mlp_train_tiles", "nrf_mlp_acts_bytes",
     "nrf_mlp_masks_bytes", "nrf_mlp_forward_rays_train", "nrf_composite_backward", "nrf_model_param_floats",
-    "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mse_grad", "nrf_clip_adam", "nrf_clip_adam_l2", "nrf_kilo_forward_packing", "nrf_kilo_pack_weights_cells", "nrf_kilo_train_workspace_bytes", "nrf_kilo_train_forward_backward", "nrf_kilo_clip_adam", "nrf_mlp_forward_rays_train_bf16x3",
+    "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mse_grad", "nrf_clip_adam", "nrf_clip_adam_l2", "nrf_kilo_forward_packing", "nrf_kilo_pack_weights_cells", "nrf_kilo_train_workspace_bytes", "nrf_kilo_train_forward_backward", "nrf_kilo_clip_adam", "nrf_mlp_forward_rays_train_bf16x3", "nrf_packed_bwd_bf16x3_bytes", "nrf_pack_weights_transposed_bf16x3",
+    "nrf_mlp_backward_bf16x3",
     "nrf_kilo_packed_floats", "nrf_kilo_pack_weights", "nrf_kilo_route", "nrf_kilo_forward_workspace_bytes",
     "nrf_kilo_forward", "nrf_kilo_march_workspace_bytes", "nrf_kilo_march_count", "nrf_kilo_march_write",
     "nrf_kilo_composite", "nrf_occ_bake_workspace_bytes", "nrf_occ_bake",
@@ -133,6 +134,12 @@ def lib() -> C.CDLL:
     L.nrf_kilo_clip_adam.restype = INT
     L.nrf_mlp_forward_rays_train_bf16x3.argtypes = [P, P, P, P, I64, I64, INT, P, P, P, P]
     L.nrf_mlp_forward_rays_train_bf16x3.restype = INT
+    L.nrf_packed_bwd_bf16x3_bytes.restype = I64
+    L.nrf_packed_bwd_bf16x3_bytes.argtypes = []
+    L.nrf_pack_weights_transposed_bf16x3.argtypes = [P, P, P]
+    L.nrf_pack_weights_transposed_bf16x3.restype = INT
+    L.nrf_mlp_backward_bf16x3.argtypes = [P, P, P, P, P, I64, INT, P, I64, P, P]
+    L.nrf_mlp_backward_bf16x3.restype = INT
     L.nrf_packed_bf16_bytes.restype = I64
     L.nrf_packed_bf16_bytes.argtypes = []
     L.nrf_pack_weights_bf16.restype = INT

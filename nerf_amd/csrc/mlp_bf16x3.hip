@@ -78,6 +78,7 @@ struct XPackLayer {
     int pre_L, post_L;
     int pre_col0, hid_col0, post_col0;
     int pair01;   // hidden-type layers: the stream opens with blocks 0 and 1 interleaved, [kb][ob in {0,1}][s2]
+    int transposed;   // backward chain: A = W^T (hidden part only): row = a column of W, k = a row of W
 };
 __device__ __forceinline__ unsigned short bf_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float bf_val(unsigned short b) { return __uint_as_float(unsigned(b) << 16); }
@@ -93,7 +94,9 @@ __global__ void xpack_layer_kernel(XPackLayer p) {
     const int h = lane >> 5, t = 8 * s2 + jj;
     const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
     float v = 0.f;
-    if (kbpos < p.pre_kb) {
+    if (p.transposed) {
+        v = p.W[int64_t(32 * kbpos + acc_row(t, h)) * p.ldw + p.hid_col0 + ob * 32 + (lane & 31)];
+    } else if (kbpos < p.pre_kb) {
         const int c = pe_col(kbpos * 16 + t, h, p.pre_L);
         if (c >= 0) v = p.W[row + p.pre_col0 + c];
     } else if (kbpos < p.pre_kb + p.hid_kb) {
@@ -152,9 +155,10 @@ __device__ __forceinline__ void xr_read(XRing& st, int slot, int step_in_chunk) 
 #pragma unroll
     for (int t = 0; t < 3; ++t) xr_read1(st, slot, step_in_chunk, t);
 }
-__device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, char* smem, int wave, int lane) {
+__device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, char* smem, int wave, int lane,
+                                         int n_chunks = kXChunks) {
     st.gbegin = stream_base + wave * (kXPieces * 1024) + lane * 16;
-    st.gend = st.gbegin + size_t(kXChunks) * kXChunkBytes;
+    st.gend = st.gbegin + size_t(n_chunks) * kXChunkBytes;
     st.gnext = st.gbegin;
     st.smem = smem;
     st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * unsigned(kXPieces * 1024));
@@ -179,6 +183,7 @@ __device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, cha
     __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 constexpr int kActRelu = 0, kActNone = int(0x80000000u);
+constexpr int kOpFwd = 0, kOpFwdSave = 1, kOpBwd = 2;   // OpIn modes
 
 // Input op of a hidden-type layer: X[kb] (three-term B fragments) from Y[kb] of the previous layer, in eight slices of
 // one register pair each (relu as max(bits, lim): lim = 0, or INT_MIN for "no activation"; 15 VALU instructions per
@@ -193,13 +198,17 @@ struct OpIn {
     float* save;
     unsigned* msave;
     unsigned mcur, mprev;
-    template <bool SAVE>
+    // backward chain (MODE kOpBwd): the layer's input is dY = relu'(h) * (y + w_alpha * dsig), masked by the sign words
+    // the training forward saved (mlp_bwd.hip: OpBwdMask) and written to `save` as the dY rows of the wgrad GEMMs
+    unsigned m[4];
+    float dsig;
+    template <int MODE>
     __device__ __forceinline__ void keep(int blk, int q, float a, float b) {
-        if (!SAVE) return;
+        if (MODE == kOpFwd) return;
         const int t0 = 2 * q, t1 = 2 * q + 1;
         save[(32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32] = a;
         save[(32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32] = b;
-        if (msave) {
+        if (MODE == kOpFwdSave && msave) {
             if (q == 0) mcur = 0u;
             mcur |= ((a > 0.f ? 1u : 0u) << t0) | ((b > 0.f ? 1u : 0u) << t1);
             if (q == 7) {
@@ -220,12 +229,23 @@ struct OpIn {
     // in-order MFMA issue for 60 cycles: the matrix pipe runs dry behind them)
     float sa, sb, ra, rb;
     unsigned p0, p1;
-    template <bool SAVE>
+    template <int MODE>
+    __device__ __forceinline__ void input(const f32x16& y, int blk, int q, float& a, float& b) {
+        if (MODE == kOpBwd) {
+            const float2 w = *reinterpret_cast<const float2*>(aw + blk * 32 + 2 * q);
+            const unsigned bits = m[blk >> 1] >> (16 * (blk & 1) + 2 * q);
+            a = (bits & 1u) ? fmaf(w.x, dsig, y[2 * q]) : 0.f;
+            b = (bits & 2u) ? fmaf(w.y, dsig, y[2 * q + 1]) : 0.f;
+        } else {
+            const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
+            a = __int_as_float(b0 > lim ? b0 : lim), b = __int_as_float(b1 > lim ? b1 : lim);
+        }
+        keep<MODE>(blk, q, a, b);
+    }
+    template <int MODE>
     __device__ __forceinline__ void sub(const f32x16& y, u32x4 (&x)[2][3], int blk, int q, int phase) {
         if (phase == 0) {
-            const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
-            sa = __int_as_float(b0 > lim ? b0 : lim), sb = __int_as_float(b1 > lim ? b1 : lim);
-            keep<SAVE>(blk, q, sa, sb);
+            input<MODE>(y, blk, q, sa, sb);
             p0 = pk_bf16(sa, sb);
             x[q / 4][0][q % 4] = p0;
         } else if (phase == 1) {
@@ -236,11 +256,10 @@ struct OpIn {
             x[q / 4][2][q % 4] = pk_bf16(__fsub_rn(ra, bf_lo(p1)), __fsub_rn(rb, bf_hi(p1)));
         }
     }
-    template <bool SAVE>
+    template <int MODE>
     __device__ __forceinline__ void pair(const f32x16& y, u32x4 (&x)[2][3], int blk, int q) {
-        const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
-        const float a = __int_as_float(b0 > lim ? b0 : lim), b = __int_as_float(b1 > lim ? b1 : lim);
-        keep<SAVE>(blk, q, a, b);
+        float a, b;
+        input<MODE>(y, blk, q, a, b);
         unsigned p0, p1, p2;
         split_pair(a, b, p0, p1, p2);
         x[q / 4][0][q % 4] = p0, x[q / 4][1][q % 4] = p1, x[q / 4][2][q % 4] = p2;
@@ -303,31 +322,33 @@ __device__ __forceinline__ void x3_pe_layer(XRing& st, int lane, const float* bi
 // opens with output blocks 0 AND 1 accumulated together (stream order [kb][ob in {0,1}][s2] for that part, see
 // xpack_layer_kernel): X[kb+1] is made in eight slices under the 24 MFMAs of k-block kb.  Block 1 accumulates into the
 // spare block Z because the previous layer's Y[1] is still needed (it becomes X[1] during k-block 0).
-template <int NOB, int NPOST, bool SAVE>
+template <int NOB, int NPOST, int MODE, int NHID = 8>
 __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float* bias_h, u32x4 (*X)[2][3],
                                                 const u32x4 (*post)[2][3], f32x16* Y, f32x16& Z, OpIn& op) {
-    constexpr int NKB = 8 + NPOST;
+    constexpr int NKB = NHID + NPOST;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto bias = [&](int ob) { return MODE == kOpBwd ? zero16 : *reinterpret_cast<const f32x16*>(bias_h + ob * 32); };
     static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
     op.begin(0, Y[0]);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) op.template pair<SAVE>(Y[0], X[0], 0, q);
-    Y[0] = *reinterpret_cast<const f32x16*>(bias_h);
-    Z = *reinterpret_cast<const f32x16*>(bias_h + 32);
+    for (int q = 0; q < 8; ++q) op.template pair<MODE>(Y[0], X[0], 0, q);
+    Y[0] = bias(0);
+    Z = bias(1);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        const bool make = kb + 1 < 8;
+        const bool make = kb + 1 < NHID;
         if (make) op.begin(kb + 1, Y[kb + 1]);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const u32x4* x = kb < 8 ? X[kb][s2] : post[kb - 8][s2];
+                const u32x4* x = kb < NHID ? X[kb][s2] : post[kb - NHID][s2];
                 const int g = b * 2 + s2;                       // which of the k-block's four steps
                 auto hook = [&](int m) {                        // 24 MFMAs: pair n / 3, sub-slice n % 3 after MFMA n
                     const int n = g * 6 + m;
-                    if (make) op.template sub<SAVE>(Y[kb + 1], X[kb + 1], kb + 1, n / 3, n % 3);
+                    if (make) op.template sub<MODE>(Y[kb + 1], X[kb + 1], kb + 1, n / 3, n % 3);
                     // the next block's bias is read one step ahead of its first MFMA (Y[2] is free: X[2] is made)
-                    if (kb == NKB - 1 && g == 3 && m == 0 && NOB > 2) Y[2] = *reinterpret_cast<const f32x16*>(bias_h + 2 * 32);
+                    if (kb == NKB - 1 && g == 3 && m == 0 && NOB > 2) Y[2] = bias(2);
                 };
                 x3_step(st, lane, kb * 4 + g, b == 0 ? Y[0] : Z, x, hook);
             }
@@ -340,10 +361,9 @@ __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 auto hook = [&](int m) {
-                    if (kb == NKB - 1 && s2 == 1 && m == 0 && ob + 1 < NOB)
-                        Y[ob + 1] = *reinterpret_cast<const f32x16*>(bias_h + (ob + 1) * 32);
+                    if (kb == NKB - 1 && s2 == 1 && m == 0 && ob + 1 < NOB) Y[ob + 1] = bias(ob + 1);
                 };
-                x3_step(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], kb < 8 ? X[kb][s2] : post[kb - 8][s2], hook);
+                x3_step(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], kb < NHID ? X[kb][s2] : post[kb - NHID][s2], hook);
             }
     }
 }
@@ -417,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
 
         u32x4 X[8][2][3];
         f32x16 Y[8], Z;
-        OpIn op{kActRelu, false, cst + (kOffAlphaW - kOffBias) + h * 16, 0.f, nullptr, nullptr, 0u, 0u, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        OpIn op{kActRelu, false, cst + (kOffAlphaW - kOffBias) + h * 16, 0.f, nullptr, nullptr, 0u, 0u, {0u, 0u, 0u, 0u}, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
         // pts_linears.0 .. 7 and feature_linear (li = 8) as ONE hidden-layer body in a run-time loop; the encoding-only
         // layer runs before li = 1 (pts_linears.0) and before li = 6 (the PE columns of the skip layer pts_linears.5,
         // network.py:58 cat([pe, h]), accumulated onto its hidden part)
@@ -428,13 +448,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
                 op.save = arow + (kActH + (li - 1) * 256) * 32;
                 op.msave = mrow + (li - 1) * 4 * 64;
             }
-            x3_hidden_layer<8, 0, SAVE>(st, lane, bias_h + li * 256, X, nullptr, Y, Z, op);
+            x3_hidden_layer<8, 0, SAVE ? kOpFwdSave : kOpFwd>(st, lane, bias_h + li * 256, X, nullptr, Y, Z, op);
         }
         float sigma = op.sigma;
         asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
         // feature -> views: no activation (saved as it is, no mask)
-        OpIn op_views{kActNone, false, nullptr, 0.f, SAVE ? arow + kActFeat * 32 : nullptr, nullptr, 0u, 0u, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
-        x3_hidden_layer<4, 1, SAVE>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, op_views);        // views_linears.0
+        OpIn op_views{kActNone, false, nullptr, 0.f, SAVE ? arow + kActFeat * 32 : nullptr, nullptr, 0u, 0u, {0u, 0u, 0u, 0u}, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        x3_hidden_layer<4, 1, SAVE ? kOpFwdSave : kOpFwd>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, op_views);        // views_linears.0
         float r = 0.f, g = 0.f, b = 0.f;
         {
             const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
@@ -460,6 +480,94 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
         if (h == 0 && valid) {
             const float* rb = cst + (kOffRgbB - kOffBias);
             raw[pidx] = make_float4(r + rb[0], g + rb[1], b + rb[2], sigma + cst[kOffAlphaB - kOffBias]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+}
+
+// ---- backward data-gradient chain on the same machinery (mlp_bwd.hip: mlp_dgrad_kernel is the fp32 MFMA form) -------
+// d(input of layer l) = W_l^T . dY_l with the transposed weights as the three-term stream (views^T, feature^T,
+// pts7^T .. pts1^T; nrf_pack_weights_transposed_bf16x3), dY_l = relu'(h_l) * d h_l from the sign words the training
+// forward saved, every dY_l written once to HBM for the (fp32) wgrad GEMMs.  The operand split of a layer's input is
+// the place where the mask, the alpha_linear term of h7 and the dY store happen (OpIn, MODE kOpBwd).
+constexpr int kXBwdSteps = 8 * 4 * 2 + 8 * kXStepsHidden;   // views^T (128 -> 256), then eight 256 x 256 layers: 1088
+constexpr int kXBwdChunks = kXBwdSteps / kXChunkSteps;      // 136
+static_assert(kXBwdSteps % kXChunkSteps == 0, "backward layers must be chunk aligned");
+
+__global__ __launch_bounds__(256, 1) void mlp_dgrad_x3_kernel(const float* __restrict__ packed,   // fp32 pack: head rows
+                                                              const char* __restrict__ packed_t,  // three-term W^T stream
+                                                              const float4* __restrict__ graw, const unsigned* __restrict__ masks,
+                                                              int64_t n_points, int64_t n_groups, float* __restrict__ dys) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    {
+        const float4* src = reinterpret_cast<const float4*>(packed + kOffBias);
+        float4* dst = reinterpret_cast<float4*>(smem + kXLdsConstOff);
+        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* cst = reinterpret_cast<const float*>(smem + kXLdsConstOff);
+    const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
+    const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
+
+    XRing st;
+    xr_start(st, packed_t, smem, wave, lane, kXBwdChunks);
+
+    for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+        const int64_t tile = tg * 4 + wave;
+        int64_t pidx = tile * 32 + j;
+        const bool valid = pidx < n_points;
+        if (!valid) pidx = n_points - 1;
+        float4 g = graw[pidx];
+        if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned* mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+        float* drow = dys + tile * (int64_t(kDyRows) * 32) + 4 * h * 32 + j;
+        if (h == 0) {  // d(raw) as 4 rows for the head wgrad jobs
+            float* r = dys + tile * (int64_t(kDyRows) * 32) + kDyRaw * 32 + j;
+            r[0] = g.x, r[32] = g.y, r[64] = g.z, r[96] = g.w;
+        }
+        u32x4 X[8][2][3];
+        f32x16 Y[8], Z;
+        // rgb_linear^T on the VALU (fp32): dYv = relu'(hv) * (W_rgb^T . d rgb), stored, and the input of views^T
+        {
+            const unsigned m0 = mrow[(8 * 4 + 0) * 64], m1 = mrow[(8 * 4 + 1) * 64];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
+                const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
+                const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
+                f32x16 v;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = fmaf(w2[t], g.z, fmaf(w1[t], g.y, w0[t] * g.x));
+                Y[kb] = mask16(v, ((kb < 2 ? m0 : m1) >> (16 * (kb & 1))) & 0xffffu);
+            }
+        }
+        // d feature = W_views[:, :256]^T . dYv: four k-blocks in (masked above: all-ones mask here; the split stores them
+        // as the dY rows of views_linears.0), eight blocks out
+        OpIn op{kActNone, false, aw, 0.f, drow + kDyV * 32, nullptr, 0u, 0u, {~0u, ~0u, ~0u, ~0u}, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        x3_hidden_layer<8, 0, kOpBwd, 4>(st, lane, nullptr, X, nullptr, Y, Z, op);
+        // li = 0: d h7 = W_feature^T . d feature (no activation between feature_linear and views_linears: all-ones mask,
+        // stored as the dY rows of feature_linear); li = 1 .. 7: layer l = 8 - li, dY_l = relu'(h_l) * d h_l (+ the
+        // alpha_linear term for h7), d h_{l-1} = W_l^T . dY_l.  One body, run-time loop.
+        for (int li = 0; li <= 7; ++li) {
+            const int l = 8 - li;
+            op.save = drow + (li == 0 ? kDyFeat : l * 256) * 32;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) op.m[w] = li == 0 ? 0xffffffffu : mrow[(l * 4 + w) * 64];
+            op.dsig = li == 1 ? g.w : 0.f;                       // h7 also feeds alpha_linear
+            x3_hidden_layer<8, 0, kOpBwd>(st, lane, nullptr, X, nullptr, Y, Z, op);
+        }
+        {   // dY_0 = relu'(h_0) * d h_0 (the encoding needs no gradient: the chain ends here)
+            OpBwdMask last;
+            last.dst = drow;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) last.m[w] = mrow[w * 64];
+            last.aw = aw;
+            last.dsig = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) (void)last(i, Y[i]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
@@ -496,6 +604,51 @@ int launch_x3(const void* packed, const float* a0, const float* a1, const float*
 
 }  // namespace
 
+// nrf_mlp_backward_bf16x3 (mlp_bwd.hip) calls this in place of mlp_dgrad_kernel
+int launch_dgrad_x3(const float* packed, const void* packed_t, const float* grad_raw, const unsigned* masks, int64_t n_points,
+                    float* dys, hipStream_t stream) {
+    const int64_t groups = (n_points / 32 + 3) / 4;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    static bool attr_set[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kXLdsBytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    mlp_dgrad_x3_kernel<<<dim3(unsigned(groups < cus ? groups : cus)), 256, kXLdsBytes, stream>>>(
+        packed, static_cast<const char*>(packed_t), reinterpret_cast<const float4*>(grad_raw), masks, n_points, groups, dys);
+    return NRF_OK;
+}
+
+NRF_EXPORT int64_t nrf_packed_bwd_bf16x3_bytes(void) { return int64_t(kXBwdSteps) * kXStepBytes; }
+
+// The backward chain's stream in the order it is consumed (mlp_fp32.hip: nrf_pack_weights_transposed), three bf16 terms
+// per weight: views^T (hidden columns only), feature^T, pts7^T .. pts1^T (pts5: hidden columns 63..318 only).
+NRF_EXPORT int nrf_pack_weights_transposed_bf16x3(const float* const* w, void* packed_t, nrf_stream_t stream_) {
+    if (!w || !packed_t) return NRF_ERR_NULL;
+    for (int i = 0; i < NRF_NUM_LAYERS; ++i)
+        if (!w[i]) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed_t)) return NRF_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned short* base = static_cast<unsigned short*>(packed_t);
+    nrf_launch_begin();
+    int step = 0;
+    auto launch = [&](const float* W, int ldw, int in_blocks, int col0) {   // in_blocks = k-blocks = rows of W / 32
+        XPackLayer p{W, base + int64_t(step) * (kXStepBytes / 2), ldw, 8, 0, in_blocks, 0, 0, 0, 0, col0, 0, 1, 1};
+        const int total = 8 * in_blocks * 2 * 512;
+        xpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+        step += 8 * in_blocks * 2;
+    };
+    launch(w[10], 283, 4, 0);   // views^T: 128 outputs of views_linears.0 contracted, 256 feature columns out
+    launch(w[8], 256, 8, 0);    // feature^T
+    for (int l = 7; l >= 1; --l) launch(w[l], l == 5 ? 319 : 256, 8, l == 5 ? 63 : 0);
+    return nrf_launch_status();
+}
+
+
 NRF_EXPORT int64_t nrf_packed_bf16x3_bytes(void) { return kXSmallFloatOff * 4 + int64_t(kSmallFloats) * 4; }
 
 NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const* b, void* packed, nrf_stream_t stream_) {
@@ -511,15 +664,15 @@ NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
         xpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
     };
-    launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0}, kXLayerStep[0]);
-    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kXLayerStep[l]);
+    launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0}, kXLayerStep[0]);
+    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[l]);
     // network.py:58 cat([input_pts, h]): hidden columns 63..318 as a plain layer, then the PE columns 0..62 accumulate
-    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0, 1}, kXLayerStep[5]);
-    launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0}, kXLayerStep[6]);
-    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kXLayerStep[7]);
-    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kXLayerStep[8]);
-    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kXLayerStep[9]);      // feature_linear
-    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256, 1}, kXLayerStep[10]);   // views_linears.0
+    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0, 1, 0}, kXLayerStep[5]);
+    launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0}, kXLayerStep[6]);
+    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[7]);
+    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[8]);
+    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[9]);      // feature_linear
+    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256, 1, 0}, kXLayerStep[10]);   // views_linears.0
     PackSmall s;
     for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
     s.bias[8] = b[8];

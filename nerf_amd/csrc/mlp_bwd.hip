@@ -22,22 +22,6 @@ namespace {
 // ------------------------------------------------------------------------------------
 // dgrad
 // ------------------------------------------------------------------------------------
-// X[i] = (Y[i] + dsig * w_alpha[i]) masked by the saved relu signs; stored as dY rows of the layer
-struct OpBwdMask {
-    float* dst;          // dys + (tile * kDyRows + first row) * 32 + 4 * h * 32 + point
-    unsigned m[4];       // sign bits of the layer's forward output, 16 per 32-row block
-    const float* aw;     // alpha weights [kb][h][t] in LDS (this lane-half's 16 at aw + kb*32)
-    float dsig;          // d(raw sigma) when the layer output also fed alpha_linear, else 0
-    __device__ __forceinline__ f32x16 operator()(int i, f32x16 y) {
-        const f32x16 w = *reinterpret_cast<const f32x16*>(aw + i * 32);
-        f32x16 v;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = fmaf(w[t], dsig, y[t]);
-        const f32x16 x = mask16(v, (m[i >> 1] >> (16 * (i & 1))) & 0xffffu);
-        store_block(dst, i, x);
-        return x;
-    }
-};
 struct OpBwdCopy {  // no activation between feature_linear and views_linears: dY8 = d(feature)
     float* dst;
     __device__ __forceinline__ f32x16 operator()(int i, f32x16 y) {
@@ -341,9 +325,10 @@ NRF_EXPORT int64_t nrf_mlp_backward_workspace_bytes(int64_t n_rays, int n_sample
     return nrf_mlp_dys_bytes(n_rays, n_samples) + slices * (256 * 320 + 256) * 4;
 }
 
-NRF_EXPORT int nrf_mlp_backward(const float* packed, const float* packed_t, const float* grad_raw, const float* acts,
-                                const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
-                                int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream_) {
+// packed_t_x3 != nullptr: the data-gradient chain on the three-term bf16 kernel (mlp_bf16x3.hip) instead of mlp_dgrad_kernel
+static int mlp_backward_impl(const float* packed, const float* packed_t, const void* packed_t_x3, const float* grad_raw,
+                             const float* acts, const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
+                             int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream_) {
     if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0) return NRF_ERR_SHAPE;
     if (!packed || !packed_t || !grad_raw || !acts || !masks || !workspace || !grad_flat) return NRF_ERR_NULL;
     if (!nrf_aligned16(packed) || !nrf_aligned16(packed_t) || !nrf_aligned16(grad_raw) || !nrf_aligned16(workspace) ||
@@ -363,8 +348,12 @@ NRF_EXPORT int nrf_mlp_backward(const float* packed, const float* packed_t, cons
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
     nrf_launch_begin();
-    mlp_dgrad_kernel<<<dim3(unsigned(groups < cus ? groups : cus)), 256, 0, stream>>>(
-        packed, packed_t, reinterpret_cast<const float4*>(grad_raw), masks, n_points, groups, dys);
+    if (packed_t_x3) {
+        if (const int rc = launch_dgrad_x3(packed, packed_t_x3, grad_raw, masks, n_points, dys, stream)) return rc;
+    } else {
+        mlp_dgrad_kernel<<<dim3(unsigned(groups < cus ? groups : cus)), 256, 0, stream>>>(
+            packed, packed_t, reinterpret_cast<const float4*>(grad_raw), masks, n_points, groups, dys);
+    }
 
     // offsets of each layer inside grad_flat
     int64_t woff[12], boff[12], o = 0;
@@ -414,4 +403,21 @@ NRF_EXPORT int nrf_mlp_backward(const float* packed, const float* packed_t, cons
     wgrad_kernel<4, 1, true><<<grid, 256, 0, stream>>>(job(kDyRaw, 3, kActHv, 128, 0, 0));
     reduce(32, 128, 3, ColMap{{128, 0}, {0, 0}, {0, 0}}, 11);
     return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_mlp_backward(const float* packed, const float* packed_t, const float* grad_raw, const float* acts,
+                                const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
+                                int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream) {
+    return mlp_backward_impl(packed, packed_t, nullptr, grad_raw, acts, masks, n_rays, n_samples, workspace, workspace_bytes,
+                             grad_flat, stream);
+}
+
+NRF_EXPORT int nrf_mlp_backward_bf16x3(const float* packed, const void* packed_t_x3, const float* grad_raw, const float* acts,
+                                       const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
+                                       int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream) {
+    if (!packed_t_x3) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed_t_x3)) return NRF_ERR_ALIGN;
+    // (the fp32 transposed stream is not read on this route: the forward pack stands in for its pointer checks)
+    return mlp_backward_impl(packed, packed, packed_t_x3, grad_raw, acts, masks, n_rays, n_samples, workspace, workspace_bytes,
+                             grad_flat, stream);
 }

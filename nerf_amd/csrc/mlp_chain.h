@@ -396,3 +396,19 @@ __device__ __forceinline__ void encode_pe_doubling(float x, float y, float z, in
     }
 }
 
+// X[i] = (Y[i] + dsig * w_alpha[i]) masked by the saved relu signs; stored as dY rows of the layer
+struct OpBwdMask {
+    float* dst;          // dys + (tile * kDyRows + first row) * 32 + 4 * h * 32 + point
+    unsigned m[4];       // sign bits of the layer's forward output, 16 per 32-row block
+    const float* aw;     // alpha weights [kb][h][t] in LDS (this lane-half's 16 at aw + kb*32)
+    float dsig;          // d(raw sigma) when the layer output also fed alpha_linear, else 0
+    __device__ __forceinline__ f32x16 operator()(int i, f32x16 y) {
+        const f32x16 w = *reinterpret_cast<const f32x16*>(aw + i * 32);
+        f32x16 v;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = fmaf(w[t], dsig, y[t]);
+        const f32x16 x = mask16(v, (m[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+        store_block(dst, i, x);
+        return x;
+    }
+};

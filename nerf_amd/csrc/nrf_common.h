@@ -116,3 +116,7 @@ __host__ __device__ inline int pe_col(int n, int h, int L) {
 
 
 }  // namespace nrf
+
+// mlp_bf16x3.hip, for nrf_mlp_backward_bf16x3 (mlp_bwd.hip): the data-gradient chain on the three-term bf16 kernel
+int launch_dgrad_x3(const float* packed, const void* packed_t, const float* grad_raw, const unsigned* masks, int64_t n_points,
+                    float* dys, hipStream_t stream);

@@ -31,8 +31,9 @@ def exponential_lr(base_lr: float, epoch: int, decay_epochs: int = 500, gamma: f
 class TrainStep:
     def __init__(self, net, device, near=2.0, far=6.0, n_coarse=64, n_importance=128, white_bkgd=True,
                  lr=5e-4, clip_value=40.0, process_group=None, forward_dtype="fp32"):
-        """``forward_dtype``: "fp32" (the fp32 MFMA kernel) or "bf16x3" -- the two forward passes on the three-term
-        bf16 kernel (fp32-class: DESIGN 3.7), which saves the same activations for the fp32 backward kernels."""
+        """``forward_dtype``: "fp32" (the fp32 MFMA kernels) or "bf16x3" -- the chain kernels (both forward passes and
+        the backward's data-gradient chain) on the three-term bf16 kernel (fp32-class: DESIGN 3.7); the forward saves
+        the same activations, and the weight-gradient GEMMs stay on the fp32 MFMA."""
         if forward_dtype not in ("fp32", "bf16x3"):
             raise ValueError(f"forward_dtype {forward_dtype!r}: expected 'fp32' or 'bf16x3'")
         self.forward_dtype = forward_dtype
@@ -75,9 +76,11 @@ class TrainStep:
     def _pack(self):
         for k, (ws, bs) in enumerate(self.models):
             self._packed[k] = ops.pack_weights(ws, bs, out=self._packed[k])
-            self._packed_t[k] = ops.pack_weights_transposed(ws, out=self._packed_t[k])
             if self.forward_dtype == "bf16x3":
                 self._packed_x3[k] = ops.pack_weights_bf16x3(ws, bs, out=self._packed_x3[k])
+                self._packed_t[k] = ops.pack_weights_transposed_bf16x3(ws, out=self._packed_t[k])
+            else:
+                self._packed_t[k] = ops.pack_weights_transposed(ws, out=self._packed_t[k])
 
     def forward_backward(self, rays_o, rays_d, gt, u, u2, u_coarse=None, u_fine=None):
         """Fills self.grad (both models, flat) and self.loss; returns the render outputs."""
@@ -100,10 +103,10 @@ class TrainStep:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         g_raw_c = ops.composite_backward(raw_c, zc, self.white, g_c)
-        ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, self._ws, out=self.grad[:n])
+        ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, self._ws, out=self.grad[:n], kind=self.forward_dtype)
         del g_raw_c, acts_c, masks_c, raw_c
         g_raw_f = ops.composite_backward(raw_f, z_f, self.white, g_f)
-        ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, self._ws, out=self.grad[n:])
+        ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, self._ws, out=self.grad[n:], kind=self.forward_dtype)
         return {"coarse_rgb_map": c_rgb, "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc}
 
     def step(self, rays_o, rays_d, gt, u, u2, u_coarse=None, u_fine=None):
