@@ -14,10 +14,8 @@
 // 5 slots, one raw barrier per chunk, the 6 refill pieces of a wave in the 6 MFMA gaps of the hand-over step.
 // Heads (alpha 256->1, rgb 128->3) are fp32 VALU dot products on the fp32 accumulators, as in the fp32 kernel.
 #include "mlp_chain.h"
+#include "split3.h"
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -43,20 +41,6 @@ constexpr int64_t kXSmallFloatOff = int64_t(kXStreamSteps) * kXStepBytes / 4;   
 constexpr int kXLdsConstOff = kXRing * kXChunkBytes;                             // 120 KiB
 constexpr int kXLdsBytes = kXLdsConstOff + kSmallFloats * 4;                     // + 12.1 KiB
 
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
-    const bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round to nearest even
-    return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ float bf_lo(unsigned r) { return __uint_as_float(r << 16); }
-__device__ __forceinline__ float bf_hi(unsigned r) { return __uint_as_float(r & 0xffff0000u); }
-
-// a pair of fp32 values -> the packed pair of each of its three bf16 terms (residuals are exact in fp32)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-    p0 = pk_bf16(a, b);
-    const float ra = __fsub_rn(a, bf_lo(p0)), rb = __fsub_rn(b, bf_hi(p0));
-    p1 = pk_bf16(ra, rb);
-    p2 = pk_bf16(__fsub_rn(ra, bf_lo(p1)), __fsub_rn(rb, bf_hi(p1)));
-}
 // a 32-row block held as 16 accumulator registers -> the B fragments [k16-step][term] of its three terms
 __device__ __forceinline__ void split_tile(const f32x16& v, u32x4 (&out)[2][3]) {
 #pragma unroll
@@ -179,8 +163,6 @@ __device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, cha
     for (int i = 0; i < kXLook; ++i) xr_read(st, i, i);
 }
 
-#define NRF_MFMA_X3(a, b, c) \
-    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 constexpr int kActRelu = 0, kActNone = int(0x80000000u);
 constexpr int kOpFwd = 0, kOpFwdSave = 1, kOpBwd = 2;   // OpIn modes

@@ -16,6 +16,7 @@
 //   reduce sums the per-slice partials and scatters into the flat gradient buffer in the
 //          reference's (out, in) state-dict layout, undoing the kernel's encoding-slot order.
 #include "mlp_chain.h"
+#include "split3.h"
 
 namespace {
 
@@ -232,6 +233,144 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgrad_kernel(WgradJob job) {
     if (tid < M) job.pbias[int64_t(slice) * M + tid] = bsum;
 }
 
+// The same GEMM on the bf16 matrix pipe with three-term operands (split3.h): dW += dY . X^T over a tile's 32 points is two
+// k16-steps of six v_mfma_f32_32x32x16_bf16 per (row block, column block) instead of sixteen v_mfma_f32_32x32x2_f32.
+// Each element is split ONCE per workgroup, on its way from the load registers into LDS, which holds the three bf16
+// planes of both operand tiles ([term][row][32 points], row stride 80 B: a wave's ds_read_b128 of 8 consecutive points
+// per lane is conflict free); a wave then reads ready-made A / B fragments.  Bias gradients (row sums of dY) are summed
+// in fp32 from the load registers (a row is the 8 float4 of 8 neighbouring lanes).
+constexpr int kX3Row = 80;   // bytes per LDS row: 32 bf16 + 16 B pad
+
+template <int NW, int KB>
+__global__ __launch_bounds__(NW * 64, 1) void wgrad_x3_kernel(WgradJob job) {
+    constexpr int NT = NW * 64;
+    constexpr int M = 32 * NW, K = 32 * KB;
+    constexpr int kPlaneA = M * kX3Row, kPlaneB = K * kX3Row;
+    extern __shared__ __attribute__((aligned(16))) char s_x3[];
+    char* sA = s_x3;                   // [3][M][80]
+    char* sB = s_x3 + 3 * kPlaneA;     // [3][K][80]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const int slice = blockIdx.x;
+    const int64_t t0 = int64_t(slice) * job.tiles_per_slice;
+    int64_t t1 = t0 + job.tiles_per_slice;
+    if (t1 > job.n_tiles) t1 = job.n_tiles;
+
+    f32x16 acc[KB];
+#pragma unroll
+    for (int a = 0; a < KB; ++a)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
+
+    constexpr int A4 = M * 8, B4 = K * 8;  // float4 pieces per tile (32 floats = 8 float4 per row)
+    constexpr int NA = (A4 + NT - 1) / NT, NB = (B4 + NT - 1) / NT;
+    static_assert(A4 % NT == 0, "every thread holds whole dY pieces (the row sums rely on it)");
+    float4 ra[NA], rb[NB];
+    float bsum[NA];   // lanes with (tid & 7) == 0: row sum of dY row (tid >> 3) + n * NT / 8
+#pragma unroll
+    for (int n = 0; n < NA; ++n) bsum[n] = 0.f;
+
+    auto load_tile = [&](int64_t tile) {
+        const float4* pa = reinterpret_cast<const float4*>(job.a + (tile * job.a_stride + job.a_row0) * 32);
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            const int p = tid + NT * n;
+            ra[n] = (p >> 3) < job.a_rows ? pa[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* xb = job.x + tile * job.x_stride * 32;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int p = tid + NT * n;
+            const int row = p >> 3;
+            if (p < B4) {
+                const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
+                rb[n] = reinterpret_cast<const float4*>(xb + src_row * 32)[p & 7];
+            }
+        }
+    };
+    // float4 = 4 consecutive points of a row -> 8 B of each of the row's three bf16 planes
+    auto put = [&](char* plane0, int plane_bytes, int p, const float4& v) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split_pair(v.x, v.y, a0, a1, a2);
+        split_pair(v.z, v.w, b0, b1, b2);
+        char* d = plane0 + (p >> 3) * kX3Row + (p & 7) * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(d + plane_bytes) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = make_uint2(a2, b2);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+            put(sA, kPlaneA, tid + NT * n, ra[n]);
+            float r = (ra[n].x + ra[n].y) + (ra[n].z + ra[n].w);
+            r += __shfl_xor(r, 1);
+            r += __shfl_xor(r, 2);
+            r += __shfl_xor(r, 4);
+            bsum[n] += r;
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int p = tid + NT * n;
+            if (p < B4) put(sB, kPlaneB, p, rb[n]);
+        }
+    };
+
+    if (t0 < t1) load_tile(t0);
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        __syncthreads();  // everyone is done reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t1) load_tile(tile + 1);  // in flight under the MFMAs below
+        const char* pa = sA + (wave * 32 + i) * kX3Row + 16 * kh;
+        const char* pb = sB + i * kX3Row + 16 * kh;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {   // 16 points per k16-step
+            u32x4 a[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const u32x4*>(pa + t * kPlaneA + 32 * s2);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                u32x4 b[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const u32x4*>(pb + t * kPlaneB + k * 32 * kX3Row + 32 * s2);
+                acc[k] = NRF_MFMA_X3(a[2], b[0], acc[k]);   // small terms first
+                acc[k] = NRF_MFMA_X3(a[0], b[2], acc[k]);
+                acc[k] = NRF_MFMA_X3(a[1], b[1], acc[k]);
+                acc[k] = NRF_MFMA_X3(a[1], b[0], acc[k]);
+                acc[k] = NRF_MFMA_X3(a[0], b[1], acc[k]);
+                acc[k] = NRF_MFMA_X3(a[0], b[0], acc[k]);
+            }
+        }
+    }
+    float* out = job.partial + int64_t(slice) * M * K;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) out[int64_t(wave * 32 + acc_row(t, kh)) * K + k * 32 + i] = acc[k][t];
+    }
+    if ((tid & 7) == 0) {
+#pragma unroll
+        for (int n = 0; n < NA; ++n) job.pbias[int64_t(slice) * M + (tid >> 3) + n * (NT / 8)] = bsum[n];
+    }
+}
+
+template <int NW, int KB>
+static int launch_wgrad_x3(const WgradJob& job, unsigned slices, hipStream_t stream) {
+    constexpr int bytes = 3 * (32 * NW + 32 * KB) * kX3Row;
+    static_assert(bytes <= 160 * 1024, "LDS budget");
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_kernel<NW, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                bytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    wgrad_x3_kernel<NW, KB><<<dim3(slices), NW * 64, bytes, stream>>>(job);
+    return NRF_OK;
+}
+
 // Column c of a wgrad job's K axis -> column of the reference weight matrix (or -1: padding).
 struct ColMap {
     int seg_cols[2];   // columns of each X segment
@@ -380,22 +519,28 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     };
     const dim3 grid(slices);
     // pts_linears.0: dY0 x encoding
-    wgrad_kernel<8, 2, false><<<grid, 512, 0, stream>>>(job(0, 256, kActPe, 64, 0, 0));
+    const bool x3 = packed_t_x3 != nullptr;   // the bf16x3 route: these GEMMs on the bf16 pipe with three-term operands
+    if (x3) { if (const int rc = launch_wgrad_x3<8, 2>(job(0, 256, kActPe, 64, 0, 0), slices, stream)) return rc; }
+    else wgrad_kernel<8, 2, false><<<grid, 512, 0, stream>>>(job(0, 256, kActPe, 64, 0, 0));
     reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 0);
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {  // cat([encoding, h4]) (network.py:58)
-            wgrad_kernel<8, 10, false><<<grid, 512, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
+            if (x3) { if (const int rc = launch_wgrad_x3<8, 10>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256), slices, stream)) return rc; }
+            else wgrad_kernel<8, 10, false><<<grid, 512, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
             reduce(256, 320, 256, ColMap{{64, 256}, {10, 0}, {0, 63}}, 5);
         } else {
-            wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0));
+            if (x3) { if (const int rc = launch_wgrad_x3<8, 8>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0), slices, stream)) return rc; }
+            else wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0));
             reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, l);
         }
     }
     // feature_linear: d feature x h7
-    wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0));
+    if (x3) { if (const int rc = launch_wgrad_x3<8, 8>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0), slices, stream)) return rc; }
+    else wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0));
     reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, 8);
     // views_linears.0: dYv x cat([feature, dir encoding]) (network.py:63)
-    wgrad_kernel<4, 9, false><<<grid, 256, 0, stream>>>(job(kDyV, 128, kActFeat, 256, kActDpe, 32));
+    if (x3) { if (const int rc = launch_wgrad_x3<4, 9>(job(kDyV, 128, kActFeat, 256, kActDpe, 32), slices, stream)) return rc; }
+    else wgrad_kernel<4, 9, false><<<grid, 256, 0, stream>>>(job(kDyV, 128, kActFeat, 256, kActDpe, 32));
     reduce(128, 288, 128, ColMap{{256, 32}, {0, 4}, {0, 256}}, 10);
     // alpha_linear: d sigma (raw row 3) x h7;  rgb_linear: d rgb (raw rows 0..2) x hv
     wgrad_kernel<4, 2, true><<<grid, 256, 0, stream>>>(job(kDyRaw + 3, 1, kActH + 7 * 256, 256, 0, 0));
