@@ -208,9 +208,9 @@ def train_bench(args, net, dev, rank, world, dist):
     from nerf_amd import ops
     from nerf_amd.camera import test_set_poses, focal_from_angle
     from nerf_amd.train import TrainStep
-    # --dtype bf16x3 (the default): the step's chain kernels (two forward passes, the backward's data-gradient chain) on the
-    # three-term bf16 kernels (fp32-class, same saved activations); the weight-gradient GEMMs are the fp32 MFMA ones either
-    # way.  --dtype fp32: everything on the fp32 MFMA.
+    # --dtype bf16x3 (the default): the step's matrix work (two forward passes, the backward's data-gradient chain, the
+    # weight-gradient GEMMs) on the three-term bf16 kernels (fp32-class, same saved activations); the alpha / rgb head
+    # rows stay on the fp32 MFMA / VALU.  --dtype fp32: everything on the fp32 MFMA.
     x3 = args.dtype == "bf16x3"
     ts = TrainStep(net, dev, forward_dtype="bf16x3" if x3 else "fp32")
     poses = test_set_poses(200)
@@ -256,17 +256,19 @@ def train_bench(args, net, dev, rank, world, dist):
             "metric": "training rays/sec (fwd+bwd+Adam step, 64 coarse + 128 fine samples/ray)",
             "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (forward and dgrad chains bf16x3: f32 operands as 3 bf16 terms, f32 accumulate; wgrad f32 MFMA)" if x3 else "f32",
+            "dtype": "f32 (matrix work bf16x3: f32 operands as 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate)" if x3 else "f32",
             "data": "synthetic (random pixels of orbit views, random gt, random-init weights)",
             "config": {"workload": "BASELINE configs[2]: NeRF training step, %d-ray batch per rank, fwd+bwd with Adam, "
                                    "data-parallel RCCL all-reduce" % R, "rays_per_rank": R, "perturb": 1,
                        "forward_kernel": "mlp_bf16x3_kernel<save>" if x3 else "mlp_fwd_kernel<save>"},
-            "roofline": {"kernel": "whole step (%s + wgrad GEMMs)" % ("mlp_bf16x3<save> + mlp_dgrad_x3" if x3 else "mlp_fwd<save> + mlp_dgrad"),
-                         "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "note": "algorithmic FLOPs of the step / wall time of the step, not one kernel; the peak is the fp32 "
-                                 "MFMA's" + (", which one third of the FLOPs (the weight-gradient GEMMs) run on -- the forward and the "
-                                             "data-gradient chain run on the bf16 pipe at 6 MFMAs per product" if x3 else "")},
+            "roofline": {"kernel": "whole step (%s)" % ("mlp_bf16x3<save> + mlp_dgrad_x3 + wgrad_x3 GEMMs" if x3 else "mlp_fwd<save> + mlp_dgrad + wgrad GEMMs"),
+                         "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12,
+                         "peak": BF16_MFMA_PEAK_TFLOPS / 6 if x3 else FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / (ms * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6 if x3 else FP32_MFMA_PEAK_TFLOPS),
+                         "traffic": None,
+                         "note": "algorithmic FLOPs of the step / wall time of the step, not one kernel; peak = " +
+                                 ("bf16 MFMA / 6 (six MFMAs per fp32 product); the step also moves ~42 GB of saved activations "
+                                  "and dY rows through HBM (DESIGN 3.5)" if x3 else "fp32 MFMA")},
             "final_loss": loss}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = train_cpu_baseline(args.cpu_seconds)

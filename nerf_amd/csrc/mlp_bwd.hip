@@ -323,23 +323,36 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_x3_kernel(WgradJob job) {
         if (tile + 1 < t1) load_tile(tile + 1);  // in flight under the MFMAs below
         const char* pa = sA + (wave * 32 + i) * kX3Row + 16 * kh;
         const char* pb = sB + i * kX3Row + 16 * kh;
+        // 2 k16-steps x KB column blocks = 2 KB groups of six MFMAs.  The fragments of group g + 1 are read under the
+        // MFMAs of group g, one ds_read_b128 per MFMA gap, and every gap is fenced: left alone the compiler sinks each
+        // read to just before its first use and every group then waits out the LDS latency twice (the kernel ran at a
+        // third of the matrix pipe that way).
+        auto frag_a = [&](int s2, int t) { return *reinterpret_cast<const u32x4*>(pa + t * kPlaneA + 32 * s2); };
+        auto frag_b = [&](int g, int t) {
+            return *reinterpret_cast<const u32x4*>(pb + t * kPlaneB + (g % KB) * 32 * kX3Row + 32 * (g / KB));
+        };
+        u32x4 a[2][3], b[2][3];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {   // 16 points per k16-step
-            u32x4 a[3];
+        for (int t = 0; t < 3; ++t) a[0][t] = frag_a(0, t), b[0][t] = frag_b(0, t);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const u32x4*>(pa + t * kPlaneA + 32 * s2);
-#pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                u32x4 b[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const u32x4*>(pb + t * kPlaneB + k * 32 * kX3Row + 32 * s2);
-                acc[k] = NRF_MFMA_X3(a[2], b[0], acc[k]);   // small terms first
-                acc[k] = NRF_MFMA_X3(a[0], b[2], acc[k]);
-                acc[k] = NRF_MFMA_X3(a[1], b[1], acc[k]);
-                acc[k] = NRF_MFMA_X3(a[1], b[0], acc[k]);
-                acc[k] = NRF_MFMA_X3(a[0], b[1], acc[k]);
-                acc[k] = NRF_MFMA_X3(a[0], b[0], acc[k]);
-            }
+        for (int g = 0; g < 2 * KB; ++g) {
+            const int k = g % KB, s2 = g / KB, cur = g & 1;
+            const bool more = g + 1 < 2 * KB;
+            const bool next_a = k == KB - 1 && s2 == 0;          // the other k16-step's A fragments, with the last group
+            u32x4(&A)[3] = a[s2];
+            u32x4(&B)[3] = b[cur];
+#define NRF_WG_GAP(ta, tb, RD)                       \
+    acc[k] = NRF_MFMA_X3(A[ta], B[tb], acc[k]);      \
+    RD;                                              \
+    __builtin_amdgcn_sched_barrier(0);
+            NRF_WG_GAP(2, 0, if (more) b[cur ^ 1][0] = frag_b(g + 1, 0))   // small terms first
+            NRF_WG_GAP(0, 2, if (more) b[cur ^ 1][1] = frag_b(g + 1, 1))
+            NRF_WG_GAP(1, 1, if (more) b[cur ^ 1][2] = frag_b(g + 1, 2))
+            NRF_WG_GAP(1, 0, if (next_a) a[1][0] = frag_a(1, 0))
+            NRF_WG_GAP(0, 1, if (next_a) a[1][1] = frag_a(1, 1))
+            NRF_WG_GAP(0, 0, if (next_a) a[1][2] = frag_a(1, 2))
+#undef NRF_WG_GAP
         }
     }
     float* out = job.partial + int64_t(slice) * M * K;
