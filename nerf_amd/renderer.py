@@ -50,15 +50,20 @@ class _RenderTrainFn(torch.autograd.Function):
         dev = rays_o.device
         bins = renderer._bins
         white = renderer.white_bkgd > 0
-        pc, pc_t = renderer._packed_model("model", dev), renderer._packed_model_t("model", dev)
-        pf, pf_t = renderer._packed_model("model_fine", dev), renderer._packed_model_t("model_fine", dev)
+        # mlp_dtype "bf16x3": both forward passes, the data-gradient chain and the weight-gradient GEMMs on the three-term
+        # bf16 kernels (fp32-class); the fp32 pack still supplies the head rows of the backward
+        kind = renderer.mlp_dtype
+        pc, pc_t = renderer._packed_model("model", dev), renderer._packed_model_t("model", dev, kind)
+        pf, pf_t = renderer._packed_model("model_fine", dev), renderer._packed_model_t("model_fine", dev, kind)
+        fc = pc if kind == "fp32" else renderer._packed_model("model", dev, kind)
+        ff = pf if kind == "fp32" else renderer._packed_model("model_fine", dev, kind)
         zc = bins if u_coarse is None else ops.perturb_samples(bins, u_coarse)
-        raw_c, acts_c, masks_c = ops.mlp_forward_rays_train(pc, rays_o, rays_d, zc)
+        raw_c, acts_c, masks_c = ops.mlp_forward_rays_train(fc, rays_o, rays_d, zc, kind)
         c_rgb, c_depth, w_c, _ = ops.composite(raw_c, zc, white, True)
         z_f = ops.sample_fine(w_c, bins, zc, u, u2, u_fine)      # integer bins + constants: no gradient
-        raw_f, acts_f, masks_f = ops.mlp_forward_rays_train(pf, rays_o, rays_d, z_f)
+        raw_f, acts_f, masks_f = ops.mlp_forward_rays_train(ff, rays_o, rays_d, z_f, kind)
         f_rgb, f_depth, _, f_acc = ops.composite(raw_f, z_f, white, False)
-        ctx.renderer, ctx.white = renderer, white
+        ctx.renderer, ctx.white, ctx.kind = renderer, white, kind
         # pc / pf / pc_t / pf_t are the renderer's cached packed buffers, rewritten in place by the next repack: they
         # are the forward's weights only while no parameter changes before backward
         ctx.params, ctx.versions = params, tuple(p._version for p in params)
@@ -74,9 +79,9 @@ class _RenderTrainFn(torch.autograd.Function):
         pc, pc_t, raw_c, zc, acts_c, masks_c, pf, pf_t, raw_f, z_f, acts_f, masks_f = ctx.saved
         r = ctx.renderer
         g_raw_c = ops.composite_backward(raw_c, zc, ctx.white, g_c_rgb, g_c_depth, None)
-        flat_c = ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, r._bwd_workspace(raw_c))
+        flat_c = ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, r._bwd_workspace(raw_c), kind=ctx.kind)
         g_raw_f = ops.composite_backward(raw_f, z_f, ctx.white, g_f_rgb, g_f_depth, g_f_acc)
-        flat_f = ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, r._bwd_workspace(raw_f))
+        flat_f = ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, r._bwd_workspace(raw_f), kind=ctx.kind)
         ctx.saved = None
         grads = []
         for flat in (flat_c, flat_f):
@@ -88,7 +93,8 @@ class _RenderTrainFn(torch.autograd.Function):
 class Renderer(nn.Module):
     """``mlp_dtype``: "fp32" (default, the reference's precision), "bf16x3" (fp32-class results from three-term bf16
     operand splits on the bf16 matrix cores, inference only) or "bf16" (BASELINE configs[4]: the MLP on the bf16
-    matrix cores, inference only; ``cfg.task_arg.mlp_dtype`` is read when the argument is None)."""
+    matrix cores, inference only -- training runs with "fp32" or "bf16x3"; ``cfg.task_arg.mlp_dtype`` is read when the
+    argument is None)."""
 
     def __init__(self, net, cfg=None, mlp_dtype: str | None = None):
         super().__init__()
@@ -238,14 +244,16 @@ class Renderer(nn.Module):
             params += [mod.weight, mod.bias]
         return params
 
-    def _packed_model_t(self, name: str, device) -> torch.Tensor:
+    def _packed_model_t(self, name: str, device, kind: str = "fp32") -> torch.Tensor:
         params = self._model_params(name)
         key = tuple((p.data_ptr(), p._version) for p in params[0::2]) + (str(device),)
-        hit = self._packed_t.get(name)
+        slot = (name, kind)
+        hit = self._packed_t.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
-        buf = ops.pack_weights_transposed(params[0::2], out=hit[1] if hit is not None else None)
-        self._packed_t[name] = (key, buf)
+        pack = ops.pack_weights_transposed if kind == "fp32" else ops.pack_weights_transposed_bf16x3
+        buf = pack(params[0::2], out=hit[1] if hit is not None else None)
+        self._packed_t[slot] = (key, buf)
         return buf
 
     def _bwd_workspace(self, raw: torch.Tensor) -> torch.Tensor:
@@ -296,8 +304,8 @@ class Renderer(nn.Module):
         u2 = torch.rand(R, ni, device=dev)
         u_fine = torch.rand((R, ni), dtype=torch.float32, device=dev) if perturbed else None
         if needs_grad:
-            if self.mlp_dtype != "fp32":
-                raise NrfError("training runs the fp32 kernels: construct the Renderer with mlp_dtype='fp32'")
+            if self.mlp_dtype == "bf16":
+                raise NrfError("training runs the fp32-class kernels: construct the Renderer with mlp_dtype='fp32' or 'bf16x3'")
             return self.render_rays_train(rays_o, rays_d, u, u2, u_coarse, u_fine)
         return self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
 

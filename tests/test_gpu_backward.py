@@ -37,7 +37,7 @@ def test_composite_backward_vs_oracle_autograd(golden, dev):
         assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), name
 
 
-def _setup(fx, dev):
+def _setup(fx, dev, mlp_dtype="fp32"):
     from nerf_amd.network import Network
     from nerf_amd.renderer import Renderer
     from nerf_amd.weights import make_state_dict
@@ -45,14 +45,18 @@ def _setup(fx, dev):
     net = Network()
     net.load_state_dict(make_state_dict(int(fx["weight_seed"]), float(fx["density_gain"]), float(fx["density_bias"])))
     net.to(dev)
-    r = Renderer(net, default_cfg(perturb=1))
+    r = Renderer(net, default_cfg(perturb=1), mlp_dtype=mlp_dtype)
     r._bins = _t(fx["t_bins"], dev)
     return net, r
 
 
-def test_training_step_gradients_match_reference(golden, dev):
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3"])
+def test_training_step_gradients_match_reference(golden, dev, mlp_dtype):
+    """Gradients of the REFERENCE's own training step (tests/golden/train_camera32.npz: autograd through the real
+    reference renderer) through Renderer's autograd route -- on the fp32 MFMA kernels and on the three-term bf16 kernels
+    (forward, data-gradient chain and weight-gradient GEMMs), same bars."""
     fx = golden("train_camera32")
-    net, r = _setup(fx, dev)
+    net, r = _setup(fx, dev, mlp_dtype)
     out = r.render_rays_train(_t(fx["xyz"], dev), _t(fx["viewdirs"], dev), _t(fx["u"], dev), _t(fx["u2"], dev),
                               _t(fx["u_coarse"], dev), _t(fx["u_fine"], dev))
     gt = _t(fx["gt_rgb"], dev)
