@@ -125,6 +125,23 @@ int nrf_mlp_forward_rays_train_bf16x3(const void* packed, const float* rays_o, c
                                       int64_t z_stride, int64_t n_rays, int n_samples, float* raw, float* acts,
                                       uint32_t* masks, nrf_stream_t stream);
 
+/* ---- fp32-class MLP on the fp16 matrix cores ("fp16x2") ------------------------------------------------------------- */
+
+/* Same network and reference path (network.py:49-74, 171-195, volume_renderer.py:227-231, 393-423).  Every fp32 weight
+ * and every layer input is split into two fp16 terms (a ~ a_hi + a_lo / 2048, both rounded to nearest even: 22
+ * significand bits) and each product is three v_mfma_f32_32x32x16_f16 (hi.hi, and hi.lo + lo.hi through a second
+ * accumulator at scale 2^11), fp32 accumulation; fp32 biases and fp32 alpha / rgb heads.  Operand error 2^-22 per
+ * product, below what an fp32 accumulation of a 256-term sum loses: results stay as close to a float64 evaluation as
+ * the fp32 reference is (tests/test_gpu_fp16x2.py), at 3 / 16 of the fp32 MFMA time on paper.  Operands must lie in
+ * fp16's range (|a| < 65520, weights and activations alike): beyond it the output is non-finite.
+ * n_samples must be a multiple of 32. */
+int64_t nrf_packed_fp16x2_bytes(void);
+int nrf_pack_weights_fp16x2(const float* const* w, const float* const* b, void* packed_h2, nrf_stream_t stream);
+int nrf_mlp_forward_rays_fp16x2(const void* packed_h2, const float* rays_o, const float* rays_d, const float* z,
+                                int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream);
+int nrf_mlp_forward_points_fp16x2(const void* packed_h2, const float* pts, const float* dirs, int64_t n_points,
+                                  float* raw, nrf_stream_t stream);
+
 /* nrf_mlp_backward with the data-gradient chain (d h_{l-1} = W_l^T dY_l) on the three-term bf16 kernel; the weight-gradient
  * GEMMs are the same fp32 kernels.  packed: nrf_pack_weights (head rows); packed_t_x3: nrf_pack_weights_transposed_bf16x3
  * (nrf_packed_bwd_bf16x3_bytes() bytes).  Same workspace, acts / masks and gradient layout as nrf_mlp_backward. */
@@ -421,6 +438,8 @@ int nrf_render(const nrf_render_args* args, nrf_stream_t stream);
 int nrf_render_bf16(const nrf_render_args* args, nrf_stream_t stream);
 /* ... and with the bf16x3 MLPs: packed_coarse / packed_fine are nrf_pack_weights_bf16x3 streams. */
 int nrf_render_bf16x3(const nrf_render_args* args, nrf_stream_t stream);
+/* ... and with the fp16x2 MLPs: packed_coarse / packed_fine are nrf_pack_weights_fp16x2 streams. */
+int nrf_render_fp16x2(const nrf_render_args* args, nrf_stream_t stream);
 
 
 /* ---- the whole forward path without any allocation ------------------------------------------------------------------

@@ -46,7 +46,7 @@ NRF_EXPORT int64_t nrf_render_workspace_bytes(int64_t n_rays, int n_coarse, int 
     return Workspace(n_rays, n_coarse, n_importance).total;
 }
 
-enum MlpKind { MLP_FP32 = 0, MLP_BF16 = 1, MLP_BF16X3 = 2 };
+enum MlpKind { MLP_FP32 = 0, MLP_BF16 = 1, MLP_BF16X3 = 2, MLP_FP16X2 = 3 };
 
 static int render_path(const nrf_render_args* a, MlpKind kind, nrf_stream_t stream) {
     if (!a) return NRF_ERR_NULL;
@@ -81,6 +81,8 @@ static int render_path(const nrf_render_args* a, MlpKind kind, nrf_stream_t stre
             return nrf_mlp_forward_rays_bf16(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
         if (kind == MLP_BF16X3)
             return nrf_mlp_forward_rays_bf16x3(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
+        if (kind == MLP_FP16X2)
+            return nrf_mlp_forward_rays_fp16x2(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
         return nrf_mlp_forward_rays(packed, a->rays_o, a->rays_d, z, z_stride, a->n_rays, n_samples, raw, stream);
     };
     if ((st = mlp(a->packed_coarse, zc, zc_stride, nc))) return st;
@@ -102,6 +104,7 @@ NRF_EXPORT int nrf_render(const nrf_render_args* a, nrf_stream_t stream) { retur
 // nrf_pack_weights_bf16 streams (BASELINE configs[4]).
 NRF_EXPORT int nrf_render_bf16(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, MLP_BF16, stream); }
 NRF_EXPORT int nrf_render_bf16x3(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, MLP_BF16X3, stream); }
+NRF_EXPORT int nrf_render_fp16x2(const nrf_render_args* a, nrf_stream_t stream) { return render_path(a, MLP_FP16X2, stream); }
 
 // ---- nrf_render without an allocation anywhere (no counterpart in the reference) ---------------------------------------
 // nrf_render's kernels need a workspace (raw, coarse weights, depths: ~4.4 KB per ray) that the caller normally brings.

@@ -13,14 +13,13 @@
 // (hi | mid | lo fragment of one k16-step of one 32-row block) through the same LDS-DMA ring: 8-step = 24-KiB chunks,
 // 5 slots, one raw barrier per chunk, the 6 refill pieces of a wave in the 6 MFMA gaps of the hand-over step.
 // Heads (alpha 256->1, rgb 128->3) are fp32 VALU dot products on the fp32 accumulators, as in the fp32 kernel.
-#include "mlp_chain.h"
+#include "split_stream.h"
 #include "split3.h"
 
 
 namespace {
 
 constexpr int kXStepBytes = 3 * 1024;                 // hi | mid | lo A fragments of one k16-step
-constexpr int kXChunkSteps = 8;
 constexpr int kXChunkBytes = kXChunkSteps * kXStepBytes;   // 24 KiB
 constexpr int kXRing = 5;
 constexpr int kXPieces = kXChunkBytes / 1024 / 4;     // LDS-DMA pieces per wave per chunk: 6
@@ -28,15 +27,6 @@ constexpr int kXPieces = kXChunkBytes / 1024 / 4;     // LDS-DMA pieces per wave
 #define X3_LOOK 2
 #endif
 constexpr int kXLook = X3_LOOK;                       // LDS -> register look-ahead of the weight fragments, in steps (< 4)
-constexpr int kXStepsL0 = 8 * 2 * 2;                  // 8 out blocks x 2 PE k-blocks x 2 k16-steps
-constexpr int kXStepsHidden = 8 * 8 * 2;              // 128
-constexpr int kXStepsViews = 4 * 9 * 2;               // 72
-// stream order (steps): pts0, pts1..4, pts5 hidden part, pts5 PE pass, pts6, pts7, feature, views
-constexpr int kXLayerStep[11] = {0, 32, 160, 288, 416, 544, 672, 704, 832, 960, 1088};
-constexpr int kXStreamSteps = 1088 + kXStepsViews;    // 1160
-constexpr int kXChunks = kXStreamSteps / kXChunkSteps;  // 145
-static_assert(kXStreamSteps % kXChunkSteps == 0 && kXStepsL0 % kXChunkSteps == 0 && kXStepsHidden % kXChunkSteps == 0 &&
-              kXStepsViews % kXChunkSteps == 0, "layers must be whole chunks");
 constexpr int64_t kXSmallFloatOff = int64_t(kXStreamSteps) * kXStepBytes / 4;   // fp32 small block behind the stream
 constexpr int kXLdsConstOff = kXRing * kXChunkBytes;                             // 120 KiB
 constexpr int kXLdsBytes = kXLdsConstOff + kSmallFloats * 4;                     // + 12.1 KiB
@@ -54,41 +44,14 @@ __device__ __forceinline__ void split_tile(const f32x16& v, u32x4 (&out)[2][3]) 
 }
 
 // ---- weight packing ------------------------------------------------------------------------
-struct XPackLayer {
-    const float* W;
-    unsigned short* dst;
-    int ldw, nob;
-    int pre_kb, hid_kb, post_kb;
-    int pre_L, post_L;
-    int pre_col0, hid_col0, post_col0;
-    int pair01;   // hidden-type layers: the stream opens with blocks 0 and 1 interleaved, [kb][ob in {0,1}][s2]
-    int transposed;   // backward chain: A = W^T (hidden part only): row = a column of W, k = a row of W
-};
 __device__ __forceinline__ unsigned short bf_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float bf_val(unsigned short b) { return __uint_as_float(unsigned(b) << 16); }
 
-__global__ void xpack_layer_kernel(XPackLayer p) {
-    const int nkb = p.pre_kb + p.hid_kb + p.post_kb;
-    const int total = p.nob * nkb * 2 * 512;  // weights (one thread writes the three terms of one weight)
+__global__ void xpack_layer_kernel(XPackLayer p) {   // one thread writes the three terms of one weight
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
-    int s2 = step & 1, kbpos = (step >> 1) % nkb, ob = (step >> 1) / nkb;
-    if (p.pair01 && step < 4 * nkb) kbpos = step >> 2, ob = (step >> 1) & 1;
-    const int h = lane >> 5, t = 8 * s2 + jj;
-    const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
-    float v = 0.f;
-    if (p.transposed) {
-        v = p.W[int64_t(32 * kbpos + acc_row(t, h)) * p.ldw + p.hid_col0 + ob * 32 + (lane & 31)];
-    } else if (kbpos < p.pre_kb) {
-        const int c = pe_col(kbpos * 16 + t, h, p.pre_L);
-        if (c >= 0) v = p.W[row + p.pre_col0 + c];
-    } else if (kbpos < p.pre_kb + p.hid_kb) {
-        v = p.W[row + p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
-    } else {
-        const int c = pe_col((kbpos - p.pre_kb - p.hid_kb) * 16 + t, h, p.post_L);
-        if (c >= 0) v = p.W[row + p.post_col0 + c];
-    }
+    if (idx >= xpack_total(p)) return;
+    int step, lane, jj;
+    const float v = xpack_fetch(p, idx, step, lane, jj);
     const unsigned short b0 = bf_bits(v);
     const float r1 = v - bf_val(b0);
     const unsigned short b1 = bf_bits(r1);
@@ -164,49 +127,9 @@ __device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, cha
 }
 
 
-constexpr int kActRelu = 0, kActNone = int(0x80000000u);
-constexpr int kOpFwd = 0, kOpFwdSave = 1, kOpBwd = 2;   // OpIn modes
-
 // Input op of a hidden-type layer: X[kb] (three-term B fragments) from Y[kb] of the previous layer, in eight slices of
-// one register pair each (relu as max(bits, lim): lim = 0, or INT_MIN for "no activation"; 15 VALU instructions per
-// slice).  The layer whose input is relu(h7) (feature_linear) also feeds alpha_linear (256 -> 1, fp32 weights, VALU).
-struct OpIn {
-    int lim;
-    bool alpha;        // run-time, uniform
-    const float* aw;   // cst + alpha weights + h * 16
-    float sigma;
-    // training forward (SAVE): the activated input of the layer goes to `save` (acts rows of this layer's input, this
-    // lane's column: mlp_fp32.hip's layout) and its relu signs to `msave` (nullptr: no activation, no mask)
-    float* save;
-    unsigned* msave;
-    unsigned mcur, mprev;
-    // backward chain (MODE kOpBwd): the layer's input is dY = relu'(h) * (y + w_alpha * dsig), masked by the sign words
-    // the training forward saved (mlp_bwd.hip: OpBwdMask) and written to `save` as the dY rows of the wgrad GEMMs
-    unsigned m[4];
-    float dsig;
-    template <int MODE>
-    __device__ __forceinline__ void keep(int blk, int q, float a, float b) {
-        if (MODE == kOpFwd) return;
-        const int t0 = 2 * q, t1 = 2 * q + 1;
-        save[(32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32] = a;
-        save[(32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32] = b;
-        if (MODE == kOpFwdSave && msave) {
-            if (q == 0) mcur = 0u;
-            mcur |= ((a > 0.f ? 1u : 0u) << t0) | ((b > 0.f ? 1u : 0u) << t1);
-            if (q == 7) {
-                if (blk & 1) msave[(blk >> 1) * 64] = mprev | (mcur << 16);
-                else mprev = mcur;
-            }
-        }
-    }
-    __device__ __forceinline__ void begin(int kb, const f32x16& y) {
-        if (alpha) {
-            const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
-            const f32x16 hx = relu16(y);
-#pragma unroll
-            for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], hx[t], sigma);
-        }
-    }
+// one register pair each (15 VALU instructions per slice behind OpInBase's activation).
+struct OpIn : OpInBase {
     // the same pair in three sub-slices of ~5 VALU instructions, one per MFMA gap (15 in one gap hold the wave's
     // in-order MFMA issue for 60 cycles: the matrix pipe runs dry behind them)
     float sa, sb, ra, rb;
@@ -419,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
 
         u32x4 X[8][2][3];
         f32x16 Y[8], Z;
-        OpIn op{kActRelu, false, cst + (kOffAlphaW - kOffBias) + h * 16, 0.f, nullptr, nullptr, 0u, 0u, {0u, 0u, 0u, 0u}, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        OpIn op{op_in(kActRelu, cst + (kOffAlphaW - kOffBias) + h * 16), 0.f, 0.f, 0.f, 0.f, 0u, 0u};
         // pts_linears.0 .. 7 and feature_linear (li = 8) as ONE hidden-layer body in a run-time loop; the encoding-only
         // layer runs before li = 1 (pts_linears.0) and before li = 6 (the PE columns of the skip layer pts_linears.5,
         // network.py:58 cat([pe, h]), accumulated onto its hidden part)
@@ -435,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
         float sigma = op.sigma;
         asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
         // feature -> views: no activation (saved as it is, no mask)
-        OpIn op_views{kActNone, false, nullptr, 0.f, SAVE ? arow + kActFeat * 32 : nullptr, nullptr, 0u, 0u, {0u, 0u, 0u, 0u}, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        OpIn op_views{op_in(kActNone, nullptr, SAVE ? arow + kActFeat * 32 : nullptr), 0.f, 0.f, 0.f, 0.f, 0u, 0u};
         x3_hidden_layer<4, 1, SAVE ? kOpFwdSave : kOpFwd>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, op_views);        // views_linears.0
         float r = 0.f, g = 0.f, b = 0.f;
         {
@@ -472,10 +395,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
 // pts7^T .. pts1^T; nrf_pack_weights_transposed_bf16x3), dY_l = relu'(h_l) * d h_l from the sign words the training
 // forward saved, every dY_l written once to HBM for the (fp32) wgrad GEMMs.  The operand split of a layer's input is
 // the place where the mask, the alpha_linear term of h7 and the dY store happen (OpIn, MODE kOpBwd).
-constexpr int kXBwdSteps = 8 * 4 * 2 + 8 * kXStepsHidden;   // views^T (128 -> 256), then eight 256 x 256 layers: 1088
-constexpr int kXBwdChunks = kXBwdSteps / kXChunkSteps;      // 136
-static_assert(kXBwdSteps % kXChunkSteps == 0, "backward layers must be chunk aligned");
-
 __global__ __launch_bounds__(256, 1) void mlp_dgrad_x3_kernel(const float* __restrict__ packed,   // fp32 pack: head rows
                                                               const char* __restrict__ packed_t,  // three-term W^T stream
                                                               const float4* __restrict__ graw, const unsigned* __restrict__ masks,
@@ -528,7 +447,9 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_x3_kernel(const float* __res
         }
         // d feature = W_views[:, :256]^T . dYv: four k-blocks in (masked above: all-ones mask here; the split stores them
         // as the dY rows of views_linears.0), eight blocks out
-        OpIn op{kActNone, false, aw, 0.f, drow + kDyV * 32, nullptr, 0u, 0u, {~0u, ~0u, ~0u, ~0u}, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        OpIn op{op_in(kActNone, aw, drow + kDyV * 32), 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) op.m[w] = ~0u;
         x3_hidden_layer<8, 0, kOpBwd, 4>(st, lane, nullptr, X, nullptr, Y, Z, op);
         // li = 0: d h7 = W_feature^T . d feature (no activation between feature_linear and views_linears: all-ones mask,
         // stored as the dY rows of feature_linear); li = 1 .. 7: layer l = 8 - li, dY_l = relu'(h_l) * d h_l (+ the
@@ -646,25 +567,8 @@ NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
         xpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
     };
-    launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0}, kXLayerStep[0]);
-    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[l]);
-    // network.py:58 cat([input_pts, h]): hidden columns 63..318 as a plain layer, then the PE columns 0..62 accumulate
-    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0, 1, 0}, kXLayerStep[5]);
-    launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0}, kXLayerStep[6]);
-    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[7]);
-    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[8]);
-    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[9]);      // feature_linear
-    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256, 1, 0}, kXLayerStep[10]);   // views_linears.0
-    PackSmall s;
-    for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
-    s.bias[8] = b[8];
-    s.bias[9] = b[10];
-    s.alpha_w = w[9];
-    s.alpha_b = b[9];
-    s.rgb_w = w[11];
-    s.rgb_b = b[11];
-    s.packed = static_cast<float*>(packed);
-    s.small_shift = kXSmallFloatOff - kOffBias;
+    xpack_forward_layers(w, launch);
+    const PackSmall s = xpack_small(w, b, packed, kXSmallFloatOff);
     pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
     return nrf_launch_status();
 }

@@ -367,6 +367,183 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_x3_kernel(WgradJob job) {
     }
 }
 
+// Pipelined form of wgrad_x3_kernel: the tile is processed in two 16-point halves (one k16-step each) through two LDS
+// stages ([stage][term][row][16 points], 48-byte rows: conflict free for the fragments' ds_read_b128), and the split of
+// half sigma + 1 runs in the MFMA gaps of half sigma -- five VALU instructions per gap hide completely under a
+// 32x32x16 MFMA -- instead of in a phase of its own between two barriers, where it and the wait for the global loads
+// cost more than the MFMAs did.  A thread owns the same float4 pieces of every tile (row (tid >> 2) + NT/4 * j, points
+// 16 h + 4 (tid & 3) ..): the registers of half h are refilled from the tile after next as soon as they have been
+// split, one half-step before they are needed again.  One barrier per half.
+constexpr int kX3HalfRow = 48;
+
+// one third of split_pair (split3.h), so that a pair's 15 instructions spread over three MFMA gaps
+__device__ __forceinline__ void split_phase(float a, float b, int phase, unsigned& p0, unsigned& p1, unsigned& p2, float& r0,
+                                            float& r1) {
+    if (phase == 0) {
+        p0 = pk_bf16(a, b);
+    } else if (phase == 1) {
+        r0 = __fsub_rn(a, bf_lo(p0)), r1 = __fsub_rn(b, bf_hi(p0));
+        p1 = pk_bf16(r0, r1);
+    } else {
+        p2 = pk_bf16(__fsub_rn(r0, bf_lo(p1)), __fsub_rn(r1, bf_hi(p1)));
+    }
+}
+
+template <int NW, int KB>
+__global__ __launch_bounds__(NW * 64, 1) void wgrad_x3p_kernel(WgradJob job) {
+    constexpr int NT = NW * 64;
+    constexpr int M = 32 * NW, K = 32 * KB;
+    constexpr int kPA = M * kX3HalfRow, kPB = K * kX3HalfRow, kStage = 3 * (kPA + kPB);
+    extern __shared__ __attribute__((aligned(16))) char s_x3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5, q = tid & 3, r0row = tid >> 2;
+    const int slice = blockIdx.x;
+    const int64_t t0 = int64_t(slice) * job.tiles_per_slice;
+    int64_t t1 = t0 + job.tiles_per_slice;
+    if (t1 > job.n_tiles) t1 = job.n_tiles;
+    const int64_t n_half = t1 > t0 ? 2 * (t1 - t0) : 0;   // half-steps of this slice
+
+    f32x16 acc[KB];
+#pragma unroll
+    for (int a = 0; a < KB; ++a)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
+
+    constexpr int NAh = M * 4 / NT;                 // float4 pieces of dY per thread and half: 2
+    constexpr int NBh = (K * 4 + NT - 1) / NT;      // ... of X
+    static_assert(M * 4 % NT == 0 && NAh >= 1, "whole dY pieces per thread");
+    constexpr int NI = NAh + NBh;                   // items per half
+    float4 reg[2][NI];                              // [half][item]: dY items first
+    float bsum[NAh];   // lanes with q == 0: row sum of dY row r0row + (NT / 4) * j
+#pragma unroll
+    for (int n = 0; n < NAh; ++n) bsum[n] = 0.f;
+
+    auto load_half = [&](int64_t hs, float4 (&r)[NI]) {   // hs = half-step index inside the slice
+        const int64_t tile = t0 + (hs >> 1);
+        const int h = int(hs & 1);
+        const float* pa = job.a + (tile * job.a_stride + job.a_row0) * 32 + (4 * h + q) * 4;
+#pragma unroll
+        for (int j = 0; j < NAh; ++j) {
+            const int row = r0row + (NT / 4) * j;
+            r[j] = row < job.a_rows ? *reinterpret_cast<const float4*>(pa + row * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* xb = job.x + tile * job.x_stride * 32 + (4 * h + q) * 4;
+#pragma unroll
+        for (int j = 0; j < NBh; ++j) {
+            const int row = r0row + (NT / 4) * j;
+            if (row < K) {
+                const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
+                r[NAh + j] = *reinterpret_cast<const float4*>(xb + src_row * 32);
+            }
+        }
+    };
+    // sub-slice w of the split of one half (items x 2 pairs x 3 phases); the item's three 8-byte stores ride on its last one
+    unsigned pa0, pa1, pa2, pb0, pb1, pb2;
+    float sr0, sr1;
+    auto split_sub = [&](char* stage, float4 (&r)[NI], int w) {
+        const int item = w / 6, ph = w % 6;
+        const bool is_a = item < NAh;
+        const int row = r0row + (NT / 4) * (is_a ? item : item - NAh);
+        if (!is_a && row >= K) return;
+        const float4 v = r[item];
+        if (ph < 3) split_phase(v.x, v.y, ph, pa0, pa1, pa2, sr0, sr1);
+        else split_phase(v.z, v.w, ph - 3, pb0, pb1, pb2, sr0, sr1);
+        if (ph == 5) {
+            char* d = stage + (is_a ? 0 : 3 * kPA) + row * kX3HalfRow + q * 8;
+            const int plane = is_a ? kPA : kPB;
+            *reinterpret_cast<uint2*>(d) = make_uint2(pa0, pb0);
+            *reinterpret_cast<uint2*>(d + plane) = make_uint2(pa1, pb1);
+            *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2(pa2, pb2);
+            if (is_a) {   // bias gradient: the row's 16 points of this half = the four lanes of a quad
+                float t = (v.x + v.y) + (v.z + v.w);
+                t += nrf_dpp<0xB1>(0.f, t);   // quad_perm [1, 0, 3, 2]
+                t += nrf_dpp<0x4E>(0.f, t);   // quad_perm [2, 3, 0, 1]
+                bsum[item] += t;
+            }
+        }
+    };
+    constexpr int W = NI * 6;          // sub-slices per half
+    constexpr int S = 6 * KB;          // MFMA gaps per half
+
+    // one half-step: MFMAs on stage `cur` (KB groups of six), the split of the next half into the other stage in the gaps
+    auto half_step = [&](const char* cur, char* nxt, float4 (&rn)[NI], bool do_split) {
+        const char* pa = cur + (wave * 32 + i) * kX3HalfRow + 16 * kh;
+        const char* pb = cur + 3 * kPA + i * kX3HalfRow + 16 * kh;
+        auto frag_b = [&](int k, int t) { return *reinterpret_cast<const u32x4*>(pb + t * kPB + k * 32 * kX3HalfRow); };
+        u32x4 a[3], b[2][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const u32x4*>(pa + t * kPA), b[0][t] = frag_b(0, t);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int c = k & 1;
+            const bool more = k + 1 < KB;
+#define NRF_WGP_GAP(m, ta, tb, RD)                                                      \
+    acc[k] = NRF_MFMA_X3(a[ta], b[c][tb], acc[k]);                                      \
+    RD;                                                                                 \
+    if (do_split) {                                                                     \
+        _Pragma("unroll") for (int w = ((k * 6 + m) * W) / S; w < ((k * 6 + m + 1) * W) / S; ++w) split_sub(nxt, rn, w); \
+    }                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+            NRF_WGP_GAP(0, 2, 0, if (more) b[c ^ 1][0] = frag_b(k + 1, 0))   // small terms first
+            NRF_WGP_GAP(1, 0, 2, if (more) b[c ^ 1][1] = frag_b(k + 1, 1))
+            NRF_WGP_GAP(2, 1, 1, if (more) b[c ^ 1][2] = frag_b(k + 1, 2))
+            NRF_WGP_GAP(3, 1, 0, (void)0)
+            NRF_WGP_GAP(4, 0, 1, (void)0)
+            NRF_WGP_GAP(5, 0, 0, (void)0)
+#undef NRF_WGP_GAP
+        }
+    };
+
+    if (n_half > 0) {
+        char* st0 = s_x3;
+        char* st1 = s_x3 + kStage;
+        load_half(0, reg[0]);
+        load_half(1, reg[1]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) split_sub(st0, reg[0], w);   // the first half: nothing to hide it under
+        __syncthreads();
+        for (int64_t hs = 0; hs < n_half; hs += 2) {
+            // even half-step: compute stage 0, split half hs + 1 (reg[1]) into stage 1; reg[0] is free: refill it
+            if (hs + 2 < n_half) load_half(hs + 2, reg[0]);
+            half_step(st0, st1, reg[1], true);
+            __syncthreads();
+            // odd half-step: compute stage 1, split half hs + 2 (reg[0]) into stage 0; refill reg[1]
+            const bool more = hs + 2 < n_half;
+            if (hs + 3 < n_half) load_half(hs + 3, reg[1]);
+            half_step(st1, st0, reg[0], more);
+            __syncthreads();
+        }
+    }
+    float* out = job.partial + int64_t(slice) * M * K;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) out[int64_t(wave * 32 + acc_row(t, kh)) * K + k * 32 + i] = acc[k][t];
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int n = 0; n < NAh; ++n) job.pbias[int64_t(slice) * M + r0row + (NT / 4) * n] = bsum[n];
+    }
+}
+
+template <int NW, int KB>
+static int launch_wgrad_x3p(const WgradJob& job, unsigned slices, hipStream_t stream) {
+    constexpr int bytes = 2 * 3 * (32 * NW + 32 * KB) * kX3HalfRow;
+    static_assert(bytes <= 160 * 1024, "LDS budget");
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3p_kernel<NW, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                bytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    wgrad_x3p_kernel<NW, KB><<<dim3(slices), NW * 64, bytes, stream>>>(job);
+    return NRF_OK;
+}
+
 template <int NW, int KB>
 static int launch_wgrad_x3(const WgradJob& job, unsigned slices, hipStream_t stream) {
     constexpr int bytes = 3 * (32 * NW + 32 * KB) * kX3Row;
@@ -542,13 +719,13 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
             else wgrad_kernel<8, 10, false><<<grid, 512, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
             reduce(256, 320, 256, ColMap{{64, 256}, {10, 0}, {0, 63}}, 5);
         } else {
-            if (x3) { if (const int rc = launch_wgrad_x3<8, 8>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0), slices, stream)) return rc; }
+            if (x3) { if (const int rc = launch_wgrad_x3p<8, 8>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0), slices, stream)) return rc; }
             else wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0));
             reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, l);
         }
     }
     // feature_linear: d feature x h7
-    if (x3) { if (const int rc = launch_wgrad_x3<8, 8>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0), slices, stream)) return rc; }
+    if (x3) { if (const int rc = launch_wgrad_x3p<8, 8>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0), slices, stream)) return rc; }
     else wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0));
     reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, 8);
     // views_linears.0: dYv x cat([feature, dir encoding]) (network.py:63)

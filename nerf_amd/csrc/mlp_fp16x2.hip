@@ -1,0 +1,486 @@
+// fp32-class 8x256 NeRF MLP on the fp16 matrix cores: every fp32 operand is split into TWO fp16 terms
+// (a ~ a_hi + a_lo / 2048, split2h.h: 22 significand bits, round to nearest even twice) and every product W.x becomes
+// THREE v_mfma_f32_32x32x16_f16: w_hi.x_lo and w_lo.x_hi into a second accumulator block that lives at scale 2^11,
+// w_hi.x_hi into the main one; a finished block is acc + 2^-11 * acc_lo.  Products of fp16 numbers are exact in the
+// MFMA's fp32 accumulate, the dropped lo.lo term and the representation error are 2^-22 of a product -- four times
+// fp32's rounding unit per operand, and still below what the reference's own fp32 accumulation of a 256-term sum
+// loses: the measured distance from a float64 evaluation stays at the fp32 reference's own (oracle restatement:
+// oracle/nerf_oracle.py:mlp_forward(split2_f16=True); tests/test_gpu_fp16x2.py holds the fp32 kernel's bars).  Three
+// MFMAs per fp32 product instead of mlp_bf16x3.hip's six (or eight fp32 MFMAs at 1/16 of the rate).  Range: operands
+// must lie inside fp16's (|a| < 65520: a trained NeRF's activations are O(10)); beyond it the output is non-finite,
+// never silently wrong.  Same reference path as mlp_fp32.hip (volume_renderer.py:227-231, 393-423, network.py:49-74,
+// 171-195, encoding/freq.py:31-32).
+//
+// Shape: mlp_bf16x3.hip's chain -- one wave = 32 points x 256 features, all 8 accumulator blocks Y of a layer live, the
+// next layer's input X made from Y just in time under the first two output blocks -- with X held as two fp16
+// B-fragment sets (128 registers), the weight stream in 2-KiB steps (hi | lo fragment of one k16-step of one 32-row
+// block) through the same LDS-DMA ring (8-step = 16-KiB chunks, 6 slots, one raw barrier per chunk), and the second
+// accumulator ping-ponging between two blocks so that a block's fold-in runs in the MFMA gaps of the next block.
+// Heads (alpha 256->1, rgb 128->3) are fp32 VALU dot products on the fp32 accumulators, as in the fp32 kernel.
+#include "split_stream.h"
+#include "split2h.h"
+
+namespace {
+
+constexpr int kHStepBytes = 2 * 1024;                 // hi | lo A fragments of one k16-step
+constexpr int kHChunkBytes = kXChunkSteps * kHStepBytes;   // 16 KiB
+#ifndef H2_RING
+#define H2_RING 6
+#endif
+constexpr int kHRing = H2_RING;
+constexpr int kHPieces = kHChunkBytes / 1024 / 4;     // LDS-DMA pieces per wave per chunk: 4
+#ifndef H2_LOOK
+#define H2_LOOK 2
+#endif
+constexpr int kHLook = H2_LOOK;                       // LDS -> register look-ahead of the weight fragments, in steps (< 4)
+constexpr int64_t kHSmallFloatOff = int64_t(kXStreamSteps) * kHStepBytes / 4;   // fp32 small block behind the stream
+constexpr int kHLdsConstOff = kHRing * kHChunkBytes;                             // 96 KiB
+constexpr int kHLdsBytes = kHLdsConstOff + kSmallFloats * 4;                     // + 12.1 KiB
+static_assert(kHLdsBytes <= 160 * 1024, "LDS budget");
+static_assert(kHPieces * (kHRing - 2) + kHLook < 64, "vmcnt is a 6-bit counter");
+
+// a 32-row block held as 16 accumulator registers -> the B fragments [k16-step][term] of its two terms
+__device__ __forceinline__ void split_tile_h(const f32x16& v, u32x4 (&out)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned hi, lo;
+            split_pair_f16(v[8 * s + 2 * i], v[8 * s + 2 * i + 1], hi, lo);
+            out[s][0][i] = hi, out[s][1][i] = lo;
+        }
+}
+
+// ---- weight packing ------------------------------------------------------------------------
+__global__ void hpack_layer_kernel(XPackLayer p) {   // one thread writes the two terms of one weight
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= xpack_total(p)) return;
+    int step, lane, jj;
+    const float v = xpack_fetch(p, idx, step, lane, jj);
+    const _Float16 hi = (_Float16)v;                                   // round to nearest even
+    const _Float16 lo = (_Float16)(__fmul_rn(__fsub_rn(v, (float)hi), kLoScale));
+    unsigned short* d = p.dst + int64_t(step) * (kHStepBytes / 2) + lane * 8 + jj;
+    d[0] = __builtin_bit_cast(unsigned short, hi), d[512] = __builtin_bit_cast(unsigned short, lo);
+}
+
+// ---- LDS ring of the 2-term stream (mlp_bf16x3.hip's XRing with 2-KiB steps) -----------------
+struct HRing {
+    const char* gnext;   // per lane: this lane's 16 B of piece 4w of the next chunk to prefetch
+    const char* gbegin;
+    const char* gend;
+    unsigned lds_base;   // LDS byte address of smem + wave * 4 KiB (this wave fills pieces 4w..4w+3)
+    char* smem;
+    int pf_slot, rd_slot;
+    const u32x4* rd;     // this lane's 16 B of term 0 of step 0 of the chunk being read
+    u32x4 wq[4][2];      // the two weight fragments of steps s .. s + kHLook - 1 (slot = step & 3), read from LDS
+                         // kHLook steps ahead of their MFMAs
+};
+__device__ __forceinline__ void hr_piece(const HRing& st, int j) {
+#ifdef H2_ABL_NODMA
+    return;
+#endif
+    glds16(st.gnext + j * 1024, __builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kHChunkBytes + j * 1024));
+}
+__device__ __forceinline__ void hr_advance(HRing& st) {
+    const char* nx = st.gnext + kHChunkBytes;
+    st.gnext = nx == st.gend ? st.gbegin : nx;
+    asm volatile("" : "+v"(st.gnext));  // keep it a run-time value (see ws_prefetch_advance)
+    st.pf_slot = st.pf_slot + 1 == kHRing ? 0 : st.pf_slot + 1;
+}
+__device__ __forceinline__ void hr_acquire(HRing& st, int lane) {
+#ifndef H2_ABL_NOBARRIER   // H2_ABL_*: timing-only ablation builds (tools/debug/h2_ab.sh): results are wrong
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(kHPieces * (kHRing - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+    st.rd_slot = st.rd_slot + 1 == kHRing ? 0 : st.rd_slot + 1;
+    st.rd = reinterpret_cast<const u32x4*>(st.smem + st.rd_slot * kHChunkBytes) + lane;
+}
+__device__ __forceinline__ void hr_read1(HRing& st, int slot, int step_in_chunk, int t) {
+#ifdef H2_ABL_NOLDS
+    return;
+#endif
+    st.wq[slot][t] = st.rd[(step_in_chunk * 2 + t) * 64];
+}
+__device__ __forceinline__ void hr_start(HRing& st, const char* stream_base, char* smem, int wave, int lane,
+                                         int n_chunks = kXChunks) {
+    st.gbegin = stream_base + wave * (kHPieces * 1024) + lane * 16;
+    st.gend = st.gbegin + size_t(n_chunks) * kHChunkBytes;
+    st.gnext = st.gbegin;
+    st.smem = smem;
+    st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * unsigned(kHPieces * 1024));
+    st.pf_slot = 0;
+    // the state of a stream in flight at step 0: chunks 0 .. kHRing-2 on their way and the last slot's refill at piece
+    // kHLook (h2_step issues piece (s + kHLook) % 8 of the current refill on step s)
+#pragma unroll
+    for (int i = 0; i < kHRing; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < (i + 1 < kHRing ? kHPieces : kHLook); ++jj) hr_piece(st, jj);
+        if (i + 1 < kHRing) hr_advance(st);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kHPieces * (kHRing - 2) + kHLook) : "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = 0;
+    st.rd = reinterpret_cast<const u32x4*>(smem) + lane;
+#pragma unroll
+    for (int i = 0; i < kHLook; ++i) {
+        hr_read1(st, i, i, 0);
+        hr_read1(st, i, i, 1);
+    }
+}
+
+// Input op of a hidden-type layer: X[kb] (two-term B fragments) from Y[kb] of the previous layer, one register pair
+// at a time in three sub-slices (activation + hi, the two residuals, lo: 3 + 2 + 2 VALU instructions).
+struct OpInH : OpInBase {
+    float sa, sb, ra, rb;
+    unsigned p0;
+    template <int MODE>
+    __device__ __forceinline__ void sub(const f32x16& y, u32x4 (&x)[2][2], int blk, int q, int phase) {
+#ifdef H2_ABL_NOSPLIT
+        return;
+#endif
+        if (phase == 0) {
+            input<MODE>(y, blk, q, sa, sb);
+            p0 = pk_f16(sa, sb);
+            x[q / 4][0][q % 4] = p0;
+        } else if (phase == 1) {
+            ra = f16_residual_lo(sa, p0), rb = f16_residual_hi(sb, p0);
+        } else {
+            x[q / 4][1][q % 4] = pk_f16_scaled(ra, rb);
+        }
+    }
+    template <int MODE>
+    __device__ __forceinline__ void pair(const f32x16& y, u32x4 (&x)[2][2], int blk, int q) {
+        float a, b;
+        input<MODE>(y, blk, q, a, b);
+        unsigned hi, lo;
+        split_pair_f16(a, b, hi, lo);
+        x[q / 4][0][q % 4] = hi, x[q / 4][1][q % 4] = lo;
+    }
+};
+
+// y[t0 .. t1) = base[t0 .. t1) + 2^-11 * yl[t0 .. t1): a slice of a finished block's fold-in
+__device__ __forceinline__ void fold_slice(f32x16& y, const f32x16& base, const f32x16& yl, int t0, int t1) {
+#ifdef H2_ABL_NOFOLD
+    return;
+#endif
+    f32x16 v = y;   // whole-vector read / write: element stores into the block array keep it out of registers
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        if (t >= t0 && t < t1) v[t] = fmaf(yl[t], kLoUnscale, base[t]);
+    y = v;
+}
+
+// One k16-step of the stream: the three MFMAs of one (output block, k16) pair -- the two cross terms into `yl` (which
+// the block's FIRST step starts from zero), hi.hi into `y`; `hook(m)` runs after MFMA m.  The ring hand-over (acquire;
+// the wave's 4 refill pieces on this and the next three steps) rides on the step kHLook before a chunk's end.  Every
+// MFMA gap is its own scheduling region (mlp_bf16x3.hip: x3_step).
+template <bool FIRST, class Hook>
+__device__ __forceinline__ void h2_step(HRing& st, int lane, int s /* stream step inside the layer */, f32x16& y, f32x16& yl,
+                                        const u32x4* x, Hook&& hook) {
+    const int piece = (s + kHLook) % kXChunkSteps;
+    const bool hand = piece == 0;
+    const u32x4 wh = st.wq[s & 3][0], wl = st.wq[s & 3][1];
+    if (hand) hr_acquire(st, lane);
+    const int rs = (s + kHLook) & 3, rc = (s + kHLook) % kXChunkSteps;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    yl = FIRST ? NRF_MFMA_F16(wh, x[1], zero16) : NRF_MFMA_F16(wh, x[1], yl);
+    hr_read1(st, rs, rc, 0);
+    hook(0);
+    __builtin_amdgcn_sched_barrier(0);
+    yl = NRF_MFMA_F16(wl, x[0], yl);
+    hr_read1(st, rs, rc, 1);
+    hook(1);
+    __builtin_amdgcn_sched_barrier(0);
+    y = NRF_MFMA_F16(wh, x[0], y);
+    if (piece < kHPieces) {
+        hr_piece(st, piece);
+        if (piece == kHPieces - 1) hr_advance(st);
+    }
+    hook(2);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Encoding-only layer (pts_linears.0, and the skip layer's PE pass which ACCUMULATES onto pts_linears.5's hidden part):
+// Y[ob] = (accum ? Y[ob] : bias) + W . pe.  `accum` is a run-time flag so both uses share one body.  Block ob's second
+// accumulator is YL[ob & 1]; it is folded in under block ob + 1 (from the third MFMA on: the result is out by then).
+__device__ __forceinline__ void h2_pe_layer(HRing& st, int lane, const float* bias_h, bool accum, const u32x4 (*pe)[2][2],
+                                            f32x16* Y, f32x16* YL) {
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) {
+        const f32x16 bias = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Y[ob][t] = accum ? Y[ob][t] : bias[t];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                auto hook = [&](int m) {
+                    const int n = (kb * 2 + s2) * 3 + m;   // 12 gaps
+                    if (ob > 0 && n >= 2 && n < 10) fold_slice(Y[ob - 1], Y[ob - 1], YL[(ob - 1) & 1], 2 * (n - 2), 2 * (n - 1));
+                };
+                if (kb == 0 && s2 == 0) h2_step<true>(st, lane, (ob * 2 + kb) * 2 + s2, Y[ob], YL[ob & 1], pe[kb][s2], hook);
+                else h2_step<false>(st, lane, (ob * 2 + kb) * 2 + s2, Y[ob], YL[ob & 1], pe[kb][s2], hook);
+            }
+    }
+    fold_slice(Y[7], Y[7], YL[1], 0, 16);
+}
+
+// Hidden-type layer: Y[ob] = bias + W . [X (NHID k-blocks), post], X[kb] = op(Y[kb] of the previous layer).
+// As in mlp_bf16x3.hip the layer opens with output blocks 0 AND 1 accumulated together (stream order
+// [kb][ob in {0,1}][s2]): X[kb+1] is made in 24 sub-slices, two per MFMA gap, under the 12 MFMAs of k-block kb.  Block 1
+// accumulates into the spare block Z because the previous layer's Y[1] is still needed (it becomes X[1] during
+// k-block 0).  Second accumulators: YL[0] for block 0 (folded in under block 1's last two steps), YL[1] for block 1
+// (folded in under block 2, together with the move Z -> Y[1]), then YL[ob & 1], each folded in under the next block;
+// the last block's fold-in is the only one that waits for its MFMAs.
+template <int NOB, int NPOST, int MODE, int NHID = 8>
+__device__ __forceinline__ void h2_hidden_layer(HRing& st, int lane, const float* bias_h, u32x4 (*X)[2][2],
+                                                const u32x4 (*post)[2][2], f32x16* Y, f32x16& Z, f32x16* YL, OpInH& op) {
+    constexpr int NKB = NHID + NPOST;
+    static_assert(NOB >= 3, "the fold-in schedule assumes a block after the paired pass");
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto bias = [&](int ob) { return MODE == kOpBwd ? zero16 : *reinterpret_cast<const f32x16*>(bias_h + ob * 32); };
+    static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
+    op.begin(0, Y[0]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) op.template pair<MODE>(Y[0], X[0], 0, q);
+    Y[0] = bias(0);
+    Z = bias(1);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const bool make = kb + 1 < NHID;
+        if (make) op.begin(kb + 1, Y[kb + 1]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4* x = kb < NHID ? X[kb][s2] : post[kb - NHID][s2];
+                const int g = b * 2 + s2;                       // which of the k-block's four steps
+                auto hook = [&](int m) {                        // 12 MFMAs: sub-slices 2n and 2n + 1 after MFMA n
+                    const int n = g * 3 + m;
+                    if (make) {
+                        op.template sub<MODE>(Y[kb + 1], X[kb + 1], kb + 1, (2 * n) / 3, (2 * n) % 3);
+                        op.template sub<MODE>(Y[kb + 1], X[kb + 1], kb + 1, (2 * n + 1) / 3, (2 * n + 1) % 3);
+                    }
+                    if (kb == NKB - 1) {
+                        // block 0 finished with step g = 1: its fold-in goes under block 1's last two steps
+                        if (n >= 8) fold_slice(Y[0], Y[0], YL[0], 4 * (n - 8), 4 * (n - 7));
+                        // the next block's bias is read one step ahead of its first MFMA (Y[2] is free: X[2] is made)
+                        if (g == 3 && m == 0) Y[2] = bias(2);
+                    }
+                };
+                if (kb == 0 && s2 == 0) h2_step<true>(st, lane, kb * 4 + g, b == 0 ? Y[0] : Z, YL[b], x, hook);
+                else h2_step<false>(st, lane, kb * 4 + g, b == 0 ? Y[0] : Z, YL[b], x, hook);
+            }
+    }
+#pragma unroll
+    for (int ob = 2; ob < NOB; ++ob) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                auto hook = [&](int m) {
+                    const int n = (kb * 2 + s2) * 3 + m;
+                    if (n >= 2 && n < 10) {   // the previous block's fold-in (block 1: out of Z)
+                        if (ob == 2) fold_slice(Y[1], Z, YL[1], 2 * (n - 2), 2 * (n - 1));
+                        else fold_slice(Y[ob - 1], Y[ob - 1], YL[(ob - 1) & 1], 2 * (n - 2), 2 * (n - 1));
+                    }
+                    if (kb == NKB - 1 && s2 == 1 && m == 0 && ob + 1 < NOB) Y[ob + 1] = bias(ob + 1);
+                };
+                const u32x4* x = kb < NHID ? X[kb][s2] : post[kb - NHID][s2];
+                if (kb == 0 && s2 == 0) h2_step<true>(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], YL[ob & 1], x, hook);
+                else h2_step<false>(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], YL[ob & 1], x, hook);
+            }
+    }
+    fold_slice(Y[NOB - 1], Y[NOB - 1], YL[(NOB - 1) & 1], 0, 16);
+}
+
+// Persistent, one 4-wave workgroup per CU, one wave per SIMD, a wave's tile = 32 points (mlp_fp32.hip's tiling).
+// SAVE (training forward): also writes every layer's activated input and relu sign bits in mlp_fwd_kernel<true>'s
+// layout, for the backward kernels of mlp_bwd.hip.
+template <bool SAVE>
+__global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restrict__ packed, const float* __restrict__ a0,
+                                                            const float* __restrict__ a1, const float* __restrict__ zbuf,
+                                                            int64_t z_stride, int tiles_per_ray, int rays_mode,
+                                                            int64_t n_points, int64_t n_groups, float4* __restrict__ raw,
+                                                            float* __restrict__ acts, unsigned* __restrict__ masks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    {
+        const float4* src = reinterpret_cast<const float4*>(packed + kHSmallFloatOff * 4);
+        float4* dst = reinterpret_cast<float4*>(smem + kHLdsConstOff);
+        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* cst = reinterpret_cast<const float*>(smem + kHLdsConstOff);
+    const float* bias_h = cst + h * 16;
+
+    HRing st;
+    hr_start(st, packed, smem, wave, lane);
+
+    for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+        const int64_t tile = tg * 4 + wave;
+        int64_t pidx = tile * 32 + j;
+        const bool valid = pidx < n_points;
+        if (!valid) pidx = n_points - 1;
+        float px, py, pz, dx, dy, dz;
+        if (rays_mode) {
+            const int64_t tile_c = pidx / 32;
+            const int64_t ray = tile_c / tiles_per_ray;
+            const int s0 = int(tile_c - ray * tiles_per_ray) * 32;
+            const float ox = a0[ray * 3 + 0], oy = a0[ray * 3 + 1], oz = a0[ray * 3 + 2];
+            dx = a1[ray * 3 + 0], dy = a1[ray * 3 + 1], dz = a1[ray * 3 + 2];
+            const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // volume_renderer.py:230 (torch's 3-element norm)
+            dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
+            const float zz = zbuf[ray * z_stride + s0 + (valid ? j : int(pidx & 31))];
+            px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
+            py = __fadd_rn(oy, __fmul_rn(zz, dy));
+            pz = __fadd_rn(oz, __fmul_rn(zz, dz));
+        } else {
+            px = a0[pidx * 3 + 0], py = a0[pidx * 3 + 1], pz = a0[pidx * 3 + 2];
+            dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
+        }
+        u32x4 pe[2][2][2], dpe[1][2][2];
+        float* arow = nullptr;     // this lane's column of the tile's saved rows (mlp_fp32.hip)
+        unsigned* mrow = nullptr;
+        if (SAVE) {
+            arow = acts + tile * (int64_t(kActRows) * 32) + 4 * h * 32 + j;
+            mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+        }
+        {
+            const f32x16 e0 = encode_block<10, 0>(px, py, pz, h), e1 = encode_block<10, 1>(px, py, pz, h);
+            const f32x16 ed = encode_block<4, 0>(dx, dy, dz, h);
+            if (SAVE) {
+                store_block(arow + kActPe * 32, 0, e0);
+                store_block(arow + kActPe * 32, 1, e1);
+                store_block(arow + kActDpe * 32, 0, ed);
+            }
+            split_tile_h(e0, pe[0]);
+            split_tile_h(e1, pe[1]);
+            split_tile_h(ed, dpe[0]);
+        }
+
+        u32x4 X[8][2][2];
+        f32x16 Y[8], Z, YL[2];
+        OpInH op{op_in(kActRelu, cst + (kOffAlphaW - kOffBias) + h * 16), 0.f, 0.f, 0.f, 0.f, 0u};
+        // pts_linears.0 .. 7 and feature_linear (li = 8) as ONE hidden-layer body in a run-time loop; the encoding-only
+        // layer runs before li = 1 (pts_linears.0) and before li = 6 (the PE columns of the skip layer pts_linears.5,
+        // network.py:58 cat([pe, h]), accumulated onto its hidden part)
+        for (int li = 1; li <= 8; ++li) {
+            if (li == 1 || li == 6) h2_pe_layer(st, lane, bias_h, li == 6, pe, Y, YL);
+            op.alpha = li == 8;                                       // feature_linear's input relu(h7) feeds alpha_linear
+            if (SAVE) {   // the layer's input h_{li-1} = relu(Y) and its signs (mask li - 1)
+                op.save = arow + (kActH + (li - 1) * 256) * 32;
+                op.msave = mrow + (li - 1) * 4 * 64;
+            }
+            h2_hidden_layer<8, 0, SAVE ? kOpFwdSave : kOpFwd>(st, lane, bias_h + li * 256, X, nullptr, Y, Z, YL, op);
+        }
+        float sigma = op.sigma;
+        asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
+        // feature -> views: no activation (saved as it is, no mask)
+        OpInH op_views{op_in(kActNone, nullptr, SAVE ? arow + kActFeat * 32 : nullptr), 0.f, 0.f, 0.f, 0.f, 0u};
+        h2_hidden_layer<4, 1, SAVE ? kOpFwdSave : kOpFwd>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, YL, op_views);   // views_linears.0
+        float r = 0.f, g = 0.f, b = 0.f;
+        {
+            const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
+            OpFwdSave<true> ops{SAVE ? arow + kActHv * 32 : nullptr, SAVE ? mrow + 8 * 4 * 64 : nullptr, 0u};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const f32x16 hv = SAVE ? ops(kb, Y[kb]) : relu16(Y[kb]);
+                const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
+                const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
+                const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    r = fmaf(w0[t], hv[t], r);
+                    g = fmaf(w1[t], hv[t], g);
+                    b = fmaf(w2[t], hv[t], b);
+                }
+            }
+        }
+        r += __shfl_xor(r, 32);
+        g += __shfl_xor(g, 32);
+        b += __shfl_xor(b, 32);
+        sigma += __shfl_xor(sigma, 32);
+        if (h == 0 && valid) {
+            const float* rb = cst + (kOffRgbB - kOffBias);
+            raw[pidx] = make_float4(r + rb[0], g + rb[1], b + rb[2], sigma + cst[kOffAlphaB - kOffBias]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+}
+
+int launch_h2(const void* packed, const float* a0, const float* a1, const float* z, int64_t z_stride, int tiles_per_ray,
+              int rays_mode, int64_t n_points, float* raw, hipStream_t stream, float* acts = nullptr, unsigned* masks = nullptr) {
+    const int64_t tiles = (n_points + 31) / 32;
+    const int64_t groups = (tiles + 3) / 4;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    static bool attr_set[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fp16x2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kHLdsBytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fp16x2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kHLdsBytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    const unsigned grid = unsigned(groups < cus ? groups : cus);
+    nrf_launch_begin();
+    if (acts)
+        mlp_fp16x2_kernel<true><<<dim3(grid), 256, kHLdsBytes, stream>>>(static_cast<const char*>(packed), a0, a1, z, z_stride,
+                                                                         tiles_per_ray, rays_mode, n_points, groups,
+                                                                         reinterpret_cast<float4*>(raw), acts, masks);
+    else
+        mlp_fp16x2_kernel<false><<<dim3(grid), 256, kHLdsBytes, stream>>>(static_cast<const char*>(packed), a0, a1, z, z_stride,
+                                                                          tiles_per_ray, rays_mode, n_points, groups,
+                                                                          reinterpret_cast<float4*>(raw), nullptr, nullptr);
+    return nrf_launch_status();
+}
+
+}  // namespace
+
+NRF_EXPORT int64_t nrf_packed_fp16x2_bytes(void) { return kHSmallFloatOff * 4 + int64_t(kSmallFloats) * 4; }
+
+NRF_EXPORT int nrf_pack_weights_fp16x2(const float* const* w, const float* const* b, void* packed, nrf_stream_t stream_) {
+    if (!w || !b || !packed) return NRF_ERR_NULL;
+    for (int i = 0; i < NRF_NUM_LAYERS; ++i)
+        if (!w[i] || !b[i]) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned short* base = static_cast<unsigned short*>(packed);
+    nrf_launch_begin();
+    auto launch = [&](XPackLayer p, int step0) {
+        p.dst = base + int64_t(step0) * (kHStepBytes / 2);
+        const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
+        hpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+    };
+    xpack_forward_layers(w, launch);
+    const PackSmall s = xpack_small(w, b, packed, kHSmallFloatOff);
+    pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_mlp_forward_rays_fp16x2(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                                           int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (!packed || !rays_o || !rays_d || !z || !raw) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
+    return launch_h2(packed, rays_o, rays_d, z, z_stride, n_samples / 32, 1, n_rays * n_samples, raw,
+                     static_cast<hipStream_t>(stream));
+}
+
+NRF_EXPORT int nrf_mlp_forward_points_fp16x2(const void* packed, const float* pts, const float* dirs, int64_t n_points,
+                                             float* raw, nrf_stream_t stream) {
+    if (n_points < 0 || n_points > (int64_t(1) << 40)) return NRF_ERR_SHAPE;
+    if (n_points == 0) return NRF_OK;
+    if (!packed || !pts || !dirs || !raw) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    return launch_h2(packed, pts, dirs, nullptr, 0, 1, 0, n_points, raw, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,53 @@
+// Two-term fp16 operand split of the fp16x2 kernels (mlp_fp16x2.hip).  fp32 a ~ a_hi + a_lo / 2048 with
+// a_hi = fp16(a) and a_lo = fp16((a - a_hi) * 2048), both round-to-nearest-even: 2 x 11 significand bits, a relative
+// representation error <= 2^-22 (1.5e-7 measured, tools/ubench/f16_probe.hip; fp32's own is 2^-24).  The residual
+// a - a_hi is exact in fp32; scaling it by 2^11 keeps a_lo a NORMAL fp16 number over the whole normal range of a_hi
+// (unscaled it would go subnormal below |a| = 2^-3 and lose bits), so the scheme holds its precision for
+// 6.1e-5 <= |a| < 65520 and degrades to an absolute error <= 2^-36 below (the matrix cores honour fp16 subnormals:
+// same probe).  |a| >= 65520 is outside the format: a_hi = inf and the output is non-finite.  A product keeps
+// hi.hi (main accumulator) and hi.lo + lo.hi (a second accumulator at scale 2^11, folded in as acc += 2^-11 * acc_lo);
+// the dropped lo.lo term is 2^-22 of the product.
+#pragma once
+#include "nrf_common.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr float kLoScale = 2048.f, kLoUnscale = 1.f / 2048.f;
+
+__device__ __forceinline__ unsigned pk_f16(float lo, float hi) {
+    const f16x2 v = {(_Float16)lo, (_Float16)hi};  // v_cvt_pk_f16_f32, round to nearest even
+    return __builtin_bit_cast(unsigned, v);
+}
+// a - (the fp16 in the low / high half of `hi`), exact: v_fma_mix_f32 reads the fp16 source in place (no unpack).
+// The asm operands are VALU results (the activation, a v_cvt_pk), never MFMA results: the compiler's MFMA -> VALU
+// hazard pass does not look inside inline asm (mlp_chain.h: relu16).
+__device__ __forceinline__ float f16_residual_lo(float a, unsigned hi) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float f16_residual_hi(float a, unsigned hi) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(hi));
+    return r;
+}
+// {fp16(ra * 2048), fp16(rb * 2048)}: scale and conversion in one instruction per half (v_fma_mixlo/hi_f16)
+__device__ __forceinline__ unsigned pk_f16_scaled(float ra, float rb) {
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(lo) : "v"(ra), "v"(kLoScale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(rb), "v"(kLoScale));
+    return lo;
+}
+// a pair of fp32 values -> the packed pairs of its two fp16 terms: 5 VALU instructions
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pk_f16(a, b);
+    lo = pk_f16_scaled(f16_residual_lo(a, hi), f16_residual_hi(b, hi));
+}
+}  // namespace
+
+#define NRF_MFMA_F16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)

@@ -146,6 +146,54 @@ def mlp_forward_points_bf16x3(packed_x3, pts, dirs) -> torch.Tensor:
     return raw
 
 
+def pack_weights_fp16x2(weights, biases, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Same inputs as pack_weights -> the two-term fp16 streaming layout of nrf_mlp_forward_rays_fp16x2 (uint8 buffer)."""
+    assert len(weights) == 12 and len(biases) == 12
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    bs = [_f32(b.detach(), "bias") for b in biases]
+    for w, b, shp in zip(ws, bs, LAYER_SHAPES):
+        if tuple(w.shape) != shp or tuple(b.shape) != (shp[0],):
+            raise _lib.NrfError(f"unexpected layer shape {tuple(w.shape)} (want {shp})")
+    dev = ws[0].device
+    if out is None:
+        out = torch.empty(int(lib().nrf_packed_fp16x2_bytes()), dtype=torch.uint8, device=dev)
+    wp = (C.c_void_p * 12)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * 12)(*[b.data_ptr() for b in bs])
+    with torch.cuda.device(dev):
+        check(lib().nrf_pack_weights_fp16x2(wp, bp, _ptr(out), _stream(out)), "nrf_pack_weights_fp16x2")
+    return out
+
+
+def pack_state_dict_fp16x2(sd: dict, prefix: str, device) -> torch.Tensor:
+    ws = [torch.as_tensor(sd[f"{prefix}.{n}.weight"]).to(device=device, dtype=torch.float32) for n in LAYER_NAMES]
+    bs = [torch.as_tensor(sd[f"{prefix}.{n}.bias"]).to(device=device, dtype=torch.float32) for n in LAYER_NAMES]
+    return pack_weights_fp16x2(ws, bs)
+
+
+def mlp_forward_rays_fp16x2(packed_h2, rays_o, rays_d, z) -> torch.Tensor:
+    rays_o, rays_d, z = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z, "z")
+    R = rays_o.shape[0]
+    S = z.shape[-1]
+    stride = 0 if z.ndim == 1 else S
+    raw = torch.empty((R, S, 4), dtype=torch.float32, device=rays_o.device)
+    with torch.cuda.device(raw.device):
+        check(lib().nrf_mlp_forward_rays_fp16x2(_ptr(packed_h2), _ptr(rays_o), _ptr(rays_d), _ptr(z), stride, R, S,
+                                                _ptr(raw), _stream(raw)), "nrf_mlp_forward_rays_fp16x2")
+    return raw
+
+
+def mlp_forward_points_fp16x2(packed_h2, pts, dirs) -> torch.Tensor:
+    pts, dirs = _f32(pts, "pts"), _f32(dirs, "dirs")
+    n = pts.shape[0]
+    if dirs.shape[0] != n:
+        raise _lib.NrfError(f"dirs has {dirs.shape[0]} rows for {n} points")
+    raw = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(raw.device):
+        check(lib().nrf_mlp_forward_points_fp16x2(_ptr(packed_h2), _ptr(pts), _ptr(dirs), n, _ptr(raw), _stream(raw)),
+              "nrf_mlp_forward_points_fp16x2")
+    return raw
+
+
 def raygen(c2w, H: int, W: int, focal: float, device, first_ray: int = 0, n_rays: int | None = None,
            pixel_index: torch.Tensor | None = None):
     c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float64)[:3, :4])

@@ -33,9 +33,11 @@ def near_far_table(near: float, far: float, n: int) -> np.ndarray:
     return (f(near) * (f(1.0) - s) + f(far) * s).astype(f)
 
 
-_PACK = {"fp32": ops.pack_weights, "bf16": ops.pack_weights_bf16, "bf16x3": ops.pack_weights_bf16x3}
-_MLP_RAYS = {"fp32": ops.mlp_forward_rays, "bf16": ops.mlp_forward_rays_bf16, "bf16x3": ops.mlp_forward_rays_bf16x3}
-_MLP_POINTS = {"fp32": ops.mlp_forward_points, "bf16": ops.mlp_forward_points_bf16, "bf16x3": ops.mlp_forward_points_bf16x3}
+_PACK = {"fp32": ops.pack_weights, "bf16": ops.pack_weights_bf16, "bf16x3": ops.pack_weights_bf16x3, "fp16x2": ops.pack_weights_fp16x2}
+_MLP_RAYS = {"fp32": ops.mlp_forward_rays, "bf16": ops.mlp_forward_rays_bf16, "bf16x3": ops.mlp_forward_rays_bf16x3,
+             "fp16x2": ops.mlp_forward_rays_fp16x2}
+_MLP_POINTS = {"fp32": ops.mlp_forward_points, "bf16": ops.mlp_forward_points_bf16, "bf16x3": ops.mlp_forward_points_bf16x3,
+               "fp16x2": ops.mlp_forward_points_fp16x2}
 
 
 class _RenderTrainFn(torch.autograd.Function):
@@ -92,7 +94,8 @@ class _RenderTrainFn(torch.autograd.Function):
 
 class Renderer(nn.Module):
     """``mlp_dtype``: "fp32" (default, the reference's precision), "bf16x3" (fp32-class results from three-term bf16
-    operand splits on the bf16 matrix cores, inference only) or "bf16" (BASELINE configs[4]: the MLP on the bf16
+    operand splits on the bf16 matrix cores), "fp16x2" (fp32-class results from two-term fp16 operand splits, 22-bit
+    operands, for networks whose weights and activations lie in fp16's range; inference only) or "bf16" (BASELINE configs[4]: the MLP on the bf16
     matrix cores, inference only -- training runs with "fp32" or "bf16x3"; ``cfg.task_arg.mlp_dtype`` is read when the
     argument is None)."""
 
@@ -115,8 +118,8 @@ class Renderer(nn.Module):
         self.far = ta.far
         self.chunk_size = ta.chunk_size if getattr(ta, "chunk_size", 0) > 0 else 1024
         self.mlp_dtype = mlp_dtype or getattr(ta, "mlp_dtype", "fp32")
-        if self.mlp_dtype not in ("fp32", "bf16", "bf16x3"):
-            raise NrfError(f"mlp_dtype {self.mlp_dtype!r}: expected 'fp32', 'bf16' or 'bf16x3'")
+        if self.mlp_dtype not in ("fp32", "bf16", "bf16x3", "fp16x2"):
+            raise NrfError(f"mlp_dtype {self.mlp_dtype!r}: expected 'fp32', 'bf16', 'bf16x3' or 'fp16x2'")
         if self.mlp_dtype == "bf16" and (self.N_samples % 64 or (self.N_samples + self.N_importance) % 64):
             raise NrfError("the bf16 MLP kernel needs sample counts that are multiples of 64")
         if self.raw_noise_std and self.raw_noise_std > 0:
@@ -304,7 +307,7 @@ class Renderer(nn.Module):
         u2 = torch.rand(R, ni, device=dev)
         u_fine = torch.rand((R, ni), dtype=torch.float32, device=dev) if perturbed else None
         if needs_grad:
-            if self.mlp_dtype == "bf16":
+            if self.mlp_dtype in ("bf16", "fp16x2"):
                 raise NrfError("training runs the fp32-class kernels: construct the Renderer with mlp_dtype='fp32' or 'bf16x3'")
             return self.render_rays_train(rays_o, rays_d, u, u2, u_coarse, u_fine)
         return self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
@@ -380,7 +383,8 @@ class Renderer(nn.Module):
                 a.coarse_rgb, a.coarse_depth = c_rgb[r0:].data_ptr(), c_depth[r0:].data_ptr()
                 a.fine_rgb, a.fine_depth, a.fine_acc = f_rgb[r0:].data_ptr(), f_depth[r0:].data_ptr(), f_acc[r0:].data_ptr()
                 a.workspace, a.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
-                entry = {"fp32": L.nrf_render, "bf16": L.nrf_render_bf16, "bf16x3": L.nrf_render_bf16x3}[self.mlp_dtype]
+                entry = {"fp32": L.nrf_render, "bf16": L.nrf_render_bf16, "bf16x3": L.nrf_render_bf16x3,
+                         "fp16x2": L.nrf_render_fp16x2}[self.mlp_dtype]
                 check(entry(C.byref(a), stream), "nrf_render")
         return {
             "coarse_rgb_map": c_rgb, "coarse_depth_map": c_depth,

@@ -129,8 +129,23 @@ def _linear_split3(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.T
     return acc + b
 
 
+def _split2_f16(t: torch.Tensor):
+    """t ~ hi + lo / 2048 with hi = fp16(t), lo = fp16((t - hi) * 2048), both round-to-nearest-even (22 significand bits):
+    what the fp16x2 kernel (mlp_fp16x2.hip, split2h.h) feeds the fp16 matrix cores."""
+    hi = t.to(torch.float16).to(t.dtype)
+    return hi, ((t - hi) * 2048.0).to(torch.float16).to(t.dtype)
+
+
+def _linear_split2_f16(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """One layer of nrf_mlp_forward_rays_fp16x2: hi.hi (+ the fp32 bias) in the main accumulator, hi.lo + lo.hi in a
+    second one at scale 2^11, result = main + 2^-11 * second (each product of two fp16 values is exact in fp32)."""
+    hh, hl = _split2_f16(h)
+    wh, wl = _split2_f16(w)
+    return (F.linear(hh, wh) + b) + (F.linear(hl, wh) + F.linear(hh, wl)) * (1.0 / 2048.0)
+
+
 def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Tensor, bf16: bool = False,
-                split3: bool = False) -> torch.Tensor:
+                split3: bool = False, split2_f16: bool = False) -> torch.Tensor:
     """``NeRF.forward`` (network.py:49-74): raw ``[r, g, b, sigma]`` per point, no activation.
 
     ``bf16=True`` restates the numerics of nrf_mlp_forward_rays_bf16 (mlp_bf16.hip): the weights and the input of
@@ -142,6 +157,8 @@ def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Te
         w = sd[f"{prefix}.{name}.weight"]
         if split3 and mfma:       # ``split3=True``: the bf16x3 kernel's rule; the alpha / rgb heads stay fp32 (VALU)
             return _linear_split3(h, w, sd[f"{prefix}.{name}.bias"])
+        if split2_f16 and mfma:   # the fp16x2 kernel's rule, same fp32 heads
+            return _linear_split2_f16(h, w, sd[f"{prefix}.{name}.bias"])
         return F.linear(q(h), q(w), sd[f"{prefix}.{name}.bias"]) if mfma else F.linear(h, w, sd[f"{prefix}.{name}.bias"])
 
     h = emb_pts
@@ -158,7 +175,8 @@ def mlp_forward(sd: dict, prefix: str, emb_pts: torch.Tensor, emb_dirs: torch.Te
 
 
 def network_forward(sd: dict, pts: torch.Tensor, dirs: torch.Tensor, model: str = "",
-                    chunk: int = 65536, dtype=None, bf16: bool = False, split3: bool = False) -> torch.Tensor:
+                    chunk: int = 65536, dtype=None, bf16: bool = False, split3: bool = False,
+                    split2_f16: bool = False) -> torch.Tensor:
     """``Network.forward`` (network.py:171-195). ``pts`` (R,S,3) with ``dirs`` (R,3), or
     ``pts`` (P,3) with ``dirs`` (P,3).  Returns (..., 4).
 
@@ -175,7 +193,7 @@ def network_forward(sd: dict, pts: torch.Tensor, dirs: torch.Tensor, model: str 
     for i in range(0, flat.shape[0], chunk):
         e = pos_enc(flat[i:i + chunk], 10)
         ed = pos_enc(dflat[i:i + chunk], 4)
-        outs.append(mlp_forward(sd, prefix, e, ed, bf16, split3))
+        outs.append(mlp_forward(sd, prefix, e, ed, bf16, split3, split2_f16))
     out = torch.cat(outs, 0)
     return out.reshape(list(pts.shape[:-1]) + [4])
 

@@ -1,5 +1,6 @@
 """Times nrf_mlp_forward_rays_bf16x3 from arbitrary builds of the library in one process (A/B of kernel variants) and
-checks that every build returns the first build's bits.  usage: x3_ablate.py <lib.so> [<lib.so> ...]"""
+checks that every build returns the first build's bits.  usage: x3_ablate.py [--kind fp16x2] <lib.so> [<lib.so> ...]
+(--kind fp16x2: nrf_mlp_forward_rays_fp16x2 from builds made by tools/debug/h2_ab.sh)"""
 import ctypes as C
 import os
 import sys
@@ -20,17 +21,21 @@ shapes = [(256, 63)] + [(256, 256)] * 4 + [(256, 319)] + [(256, 256)] * 3 + [(1,
 ws = [torch.randn(s, device=dev, generator=torch.Generator(device=dev).manual_seed(i)) * 0.05 for i, s in enumerate(shapes)]
 bs = [torch.zeros(s[0], device=dev) for s in shapes]
 first = None
-for path in sys.argv[1:]:
+paths = sys.argv[1:]
+kind = "bf16x3"
+if paths and paths[0] == "--kind":
+    kind, paths = paths[1], paths[2:]
+for path in paths:
     L = C.CDLL(os.path.abspath(path))
-    L.nrf_packed_bf16x3_bytes.restype = C.c_int64
-    packed = torch.zeros(L.nrf_packed_bf16x3_bytes(), dtype=torch.uint8, device=dev)
+    getattr(L, f"nrf_packed_{kind}_bytes").restype = C.c_int64
+    packed = torch.zeros(getattr(L, f"nrf_packed_{kind}_bytes")(), dtype=torch.uint8, device=dev)
     wp = (P * 12)(*[w.data_ptr() for w in ws])
     bp = (P * 12)(*[b.data_ptr() for b in bs])
-    assert L.nrf_pack_weights_bf16x3(wp, bp, P(packed.data_ptr()), None) == 0
+    assert getattr(L, f"nrf_pack_weights_{kind}")(wp, bp, P(packed.data_ptr()), None) == 0
     raw = torch.empty(R, S, 4, device=dev)
 
     def run():
-        st = L.nrf_mlp_forward_rays_bf16x3(P(packed.data_ptr()), P(o.data_ptr()), P(d.data_ptr()), P(z.data_ptr()),
+        st = getattr(L, f"nrf_mlp_forward_rays_{kind}")(P(packed.data_ptr()), P(o.data_ptr()), P(d.data_ptr()), P(z.data_ptr()),
                                            C.c_int64(S), C.c_int64(R), C.c_int(S), P(raw.data_ptr()), None)
         assert st == 0, st
     run()

@@ -19,7 +19,8 @@ from nerf_amd.weights import make_state_dict_arrays  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--only", default="all", choices=["all", "mlp", "composite", "sample", "bf16", "bf16x3", "kilo", "train"])
+ap.add_argument("--train-dtype", default="bf16x3", choices=["fp32", "bf16x3"], help="--only train: TrainStep's forward_dtype")
+ap.add_argument("--only", default="all", choices=["all", "mlp", "composite", "sample", "bf16", "bf16x3", "fp16x2", "kilo", "train"])
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -48,7 +49,7 @@ if a.only == "train":       # NeRF training step (BASELINE configs[2]): mlp_fwd<
     from nerf_amd.weights import make_state_dict
     net = Network()
     net.load_state_dict(make_state_dict(0, 30.0, 2.0))
-    ts = TrainStep(net.to(dev), dev)
+    ts = TrainStep(net.to(dev), dev, forward_dtype=a.train_dtype)
     R = 4096
     g = torch.Generator(device=dev).manual_seed(0)
     pix = torch.randint(0, 640000, (R,), device=dev, generator=g)
@@ -86,6 +87,22 @@ if a.only == "bf16x3":      # mlp_bf16x3_kernel, coarse + fine launch per rep
         ops.mlp_forward_rays_bf16x3(xf, o, d, z_f)
     torch.cuda.synchronize()
     print("done bf16x3")
+    sys.exit(0)
+if a.only == "fp16x2":      # mlp_fp16x2_kernel, coarse + fine launch per rep, event-timed
+    hc, hf = ops.pack_state_dict_fp16x2(sd, "model", dev), ops.pack_state_dict_fp16x2(sd, "model_fine", dev)
+    xf = ops.pack_state_dict_bf16x3(sd, "model_fine", dev)
+    for name, fn, pk in (("fp16x2", ops.mlp_forward_rays_fp16x2, hf), ("bf16x3", ops.mlp_forward_rays_bf16x3, xf)):
+        fn(pk, o, d, z_f)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            fn(pk, o, d, z_f)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"{name}: fine pass {a.rays} rays x {z_f.shape[-1]}: {e0.elapsed_time(e1) / a.reps:.3f} ms")
+    ops.mlp_forward_rays_fp16x2(hc, o, d, bins)
+    torch.cuda.synchronize()
+    print("done fp16x2")
     sys.exit(0)
 for _ in range(a.reps):
     if a.only in ("all", "mlp"):
