@@ -34,7 +34,8 @@ typedef enum nrf_status {
     NRF_ERR_WORKSPACE = -4,  /* workspace too small */
     NRF_ERR_ALIGN = -5,      /* a pointer is not 16-byte aligned */
     NRF_ERR_STATIC_LIMIT = -6, /* nrf_render_static: more rays / samples than the static scratch holds */
-    NRF_ERR_RUNTIME = -7     /* a HIP runtime query failed (hipGetDevice, hipGetSymbolAddress) */
+    NRF_ERR_RUNTIME = -7,    /* a HIP runtime query failed (hipGetDevice, hipGetSymbolAddress) */
+    NRF_ERR_RANGE = -8       /* nrf_packed_fp16x2_status: a weight lies outside fp16's range */
 } nrf_status;
 
 /* Layer order used by every `w[12]` / `b[12]` argument: the reference's state-dict layout
@@ -137,6 +138,10 @@ int nrf_mlp_forward_rays_train_bf16x3(const void* packed, const float* rays_o, c
  * n_samples must be a multiple of 32. */
 int64_t nrf_packed_fp16x2_bytes(void);
 int nrf_pack_weights_fp16x2(const float* const* w, const float* const* b, void* packed_h2, nrf_stream_t stream);
+/* Did every weight fit?  NRF_OK, or NRF_ERR_RANGE if the packer met |w| >= 65520 or a non-finite weight (the forward
+ * entry points then return NaN for every point; so does a point whose activations leave the range).  Waits for the
+ * stream: the packer itself stays asynchronous. */
+int nrf_packed_fp16x2_status(const void* packed_h2, nrf_stream_t stream);
 int nrf_mlp_forward_rays_fp16x2(const void* packed_h2, const float* rays_o, const float* rays_d, const float* z,
                                 int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream);
 int nrf_mlp_forward_points_fp16x2(const void* packed_h2, const float* pts, const float* dirs, int64_t n_points,

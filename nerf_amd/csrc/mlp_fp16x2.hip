@@ -8,7 +8,8 @@
 // oracle/nerf_oracle.py:mlp_forward(split2_f16=True); tests/test_gpu_fp16x2.py holds the fp32 kernel's bars).  Three
 // MFMAs per fp32 product instead of mlp_bf16x3.hip's six (or eight fp32 MFMAs at 1/16 of the rate).  Range: operands
 // must lie inside fp16's (|a| < 65520: a trained NeRF's activations are O(10)); beyond it the output is non-finite,
-// never silently wrong.  Same reference path as mlp_fp32.hip (volume_renderer.py:227-231, 393-423, network.py:49-74,
+// and the kernel says so: a point whose activations (or a network whose weights)
+// leave the range comes out as NaN, never as a finite wrong number.  Same reference path as mlp_fp32.hip (volume_renderer.py:227-231, 393-423, network.py:49-74,
 // 171-195, encoding/freq.py:31-32).
 //
 // Shape: mlp_bf16x3.hip's chain -- one wave = 32 points x 256 features, all 8 accumulator blocks Y of a layer live, the
@@ -34,6 +35,8 @@ constexpr int kHPieces = kHChunkBytes / 1024 / 4;     // LDS-DMA pieces per wave
 #endif
 constexpr int kHLook = H2_LOOK;                       // LDS -> register look-ahead of the weight fragments, in steps (< 4)
 constexpr int64_t kHSmallFloatOff = int64_t(kXStreamSteps) * kHStepBytes / 4;   // fp32 small block behind the stream
+constexpr int64_t kHStatusOff = kHSmallFloatOff * 4 + int64_t(kSmallFloats) * 4;   // bytes: one status word behind the small block
+constexpr float kF16Limit = 65520.f;                  // |a| >= this rounds to fp16 infinity
 constexpr int kHLdsConstOff = kHRing * kHChunkBytes;                             // 96 KiB
 constexpr int kHLdsBytes = kHLdsConstOff + kSmallFloats * 4;                     // + 12.1 KiB
 static_assert(kHLdsBytes <= 160 * 1024, "LDS budget");
@@ -52,11 +55,12 @@ __device__ __forceinline__ void split_tile_h(const f32x16& v, u32x4 (&out)[2][2]
 }
 
 // ---- weight packing ------------------------------------------------------------------------
-__global__ void hpack_layer_kernel(XPackLayer p) {   // one thread writes the two terms of one weight
+__global__ void hpack_layer_kernel(XPackLayer p, unsigned* status) {   // one thread writes the two terms of one weight
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= xpack_total(p)) return;
     int step, lane, jj;
     const float v = xpack_fetch(p, idx, step, lane, jj);
+    if (!(fabsf(v) < kF16Limit)) atomicOr(status, 1u);   // outside fp16 (or not a number): the kernel will say so
     const _Float16 hi = (_Float16)v;                                   // round to nearest even
     const _Float16 lo = (_Float16)(__fmul_rn(__fsub_rn(v, (float)hi), kLoScale));
     unsigned short* d = p.dst + int64_t(step) * (kHStepBytes / 2) + lane * 8 + jj;
@@ -75,11 +79,28 @@ struct HRing {
     u32x4 wq[4][2];      // the two weight fragments of steps s .. s + kHLook - 1 (slot = step & 3), read from LDS
                          // kHLook steps ahead of their MFMAs
 };
-__device__ __forceinline__ void hr_piece(const HRing& st, int j) {
+// piece j of the wave's share of the chunk being prefetched: the j KiB go into the instruction's offset field (no 64-bit
+// add per piece; the LDS-DMA adds the same offset to its LDS address, so M0 = the chunk's slot for all four pieces;
+// mlp_chain.h: glds16 on why this is inline asm)
+template <int J>
+__device__ __forceinline__ void hr_piece_imm(const HRing& st) {
 #ifdef H2_ABL_NODMA
     return;
 #endif
-    glds16(st.gnext + j * 1024, __builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kHChunkBytes + j * 1024));
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off offset:%2"
+        :
+        : "v"(st.gnext), "s"(__builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kHChunkBytes)), "n"(J * 1024)
+        : "memory");
+}
+__device__ __forceinline__ void hr_piece(const HRing& st, int j) {
+    static_assert(kHPieces == 4, "one case per piece");
+    if (j == 0) hr_piece_imm<0>(st);
+    else if (j == 1) hr_piece_imm<1>(st);
+    else if (j == 2) hr_piece_imm<2>(st);
+    else hr_piece_imm<3>(st);
 }
 __device__ __forceinline__ void hr_advance(HRing& st) {
     const char* nx = st.gnext + kHChunkBytes;
@@ -128,11 +149,17 @@ __device__ __forceinline__ void hr_start(HRing& st, const char* stream_base, cha
     }
 }
 
+// ovf = max(ovf, |a|, |b|) in one instruction.  The operands are VALU results (see split2h.h on inline asm and MFMAs).
+__device__ __forceinline__ void track_max(float& ovf, float a, float b) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovf) : "v"(a), "v"(b));
+}
+
 // Input op of a hidden-type layer: X[kb] (two-term B fragments) from Y[kb] of the previous layer, one register pair
 // at a time in three sub-slices (activation + hi, the two residuals, lo: 3 + 2 + 2 VALU instructions).
 struct OpInH : OpInBase {
     float sa, sb, ra, rb;
     unsigned p0;
+    float ovf;   // range guard: the largest |operand| this point has fed to a split so far
     template <int MODE>
     __device__ __forceinline__ void sub(const f32x16& y, u32x4 (&x)[2][2], int blk, int q, int phase) {
 #ifdef H2_ABL_NOSPLIT
@@ -144,6 +171,7 @@ struct OpInH : OpInBase {
             x[q / 4][0][q % 4] = p0;
         } else if (phase == 1) {
             ra = f16_residual_lo(sa, p0), rb = f16_residual_hi(sb, p0);
+            track_max(ovf, sa, sb);
         } else {
             x[q / 4][1][q % 4] = pk_f16_scaled(ra, rb);
         }
@@ -154,6 +182,7 @@ struct OpInH : OpInBase {
         input<MODE>(y, blk, q, a, b);
         unsigned hi, lo;
         split_pair_f16(a, b, hi, lo);
+        track_max(ovf, a, b);
         x[q / 4][0][q % 4] = hi, x[q / 4][1][q % 4] = lo;
     }
 };
@@ -313,6 +342,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
         float4* dst = reinterpret_cast<float4*>(smem + kHLdsConstOff);
         for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
     }
+    // a weight outside fp16's range was seen by the packer: every output is NaN (nrf_packed_fp16x2_status says why)
+    const float poison = *reinterpret_cast<const unsigned*>(packed + kHStatusOff) ? __builtin_inff() : 0.f;
     __syncthreads();
     const float* cst = reinterpret_cast<const float*>(smem + kHLdsConstOff);
     const float* bias_h = cst + h * 16;
@@ -364,7 +395,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
 
         u32x4 X[8][2][2];
         f32x16 Y[8], Z, YL[2];
-        OpInH op{op_in(kActRelu, cst + (kOffAlphaW - kOffBias) + h * 16), 0.f, 0.f, 0.f, 0.f, 0u};
+        OpInH op{op_in(kActRelu, cst + (kOffAlphaW - kOffBias) + h * 16), 0.f, 0.f, 0.f, 0.f, 0u, poison};
+        track_max(op.ovf, px, py);   // the raw coordinates are operands too (the encoding's sin / cos cannot overflow)
+        track_max(op.ovf, pz, pz);
         // pts_linears.0 .. 7 and feature_linear (li = 8) as ONE hidden-layer body in a run-time loop; the encoding-only
         // layer runs before li = 1 (pts_linears.0) and before li = 6 (the PE columns of the skip layer pts_linears.5,
         // network.py:58 cat([pe, h]), accumulated onto its hidden part)
@@ -380,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
         float sigma = op.sigma;
         asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
         // feature -> views: no activation (saved as it is, no mask)
-        OpInH op_views{op_in(kActNone, nullptr, SAVE ? arow + kActFeat * 32 : nullptr), 0.f, 0.f, 0.f, 0.f, 0u};
+        OpInH op_views{op_in(kActNone, nullptr, SAVE ? arow + kActFeat * 32 : nullptr), 0.f, 0.f, 0.f, 0.f, 0u, op.ovf};
         h2_hidden_layer<4, 1, SAVE ? kOpFwdSave : kOpFwd>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, YL, op_views);   // views_linears.0
         float r = 0.f, g = 0.f, b = 0.f;
         {
@@ -404,9 +437,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
         g += __shfl_xor(g, 32);
         b += __shfl_xor(b, 32);
         sigma += __shfl_xor(sigma, 32);
+        float ovf = op_views.ovf;
+        ovf = fmaxf(ovf, __shfl_xor(ovf, 32));
         if (h == 0 && valid) {
             const float* rb = cst + (kOffRgbB - kOffBias);
-            raw[pidx] = make_float4(r + rb[0], g + rb[1], b + rb[2], sigma + cst[kOffAlphaB - kOffBias]);
+            float4 o = make_float4(r + rb[0], g + rb[1], b + rb[2], sigma + cst[kOffAlphaB - kOffBias]);
+            // an operand of this point left fp16's range somewhere on the way: refuse it
+            if (!(ovf < kF16Limit)) o = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            raw[pidx] = o;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
@@ -443,7 +481,7 @@ int launch_h2(const void* packed, const float* a0, const float* a1, const float*
 
 }  // namespace
 
-NRF_EXPORT int64_t nrf_packed_fp16x2_bytes(void) { return kHSmallFloatOff * 4 + int64_t(kSmallFloats) * 4; }
+NRF_EXPORT int64_t nrf_packed_fp16x2_bytes(void) { return kHStatusOff + 16; }
 
 NRF_EXPORT int nrf_pack_weights_fp16x2(const float* const* w, const float* const* b, void* packed, nrf_stream_t stream_) {
     if (!w || !b || !packed) return NRF_ERR_NULL;
@@ -452,16 +490,30 @@ NRF_EXPORT int nrf_pack_weights_fp16x2(const float* const* w, const float* const
     if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     unsigned short* base = static_cast<unsigned short*>(packed);
+    unsigned* status = reinterpret_cast<unsigned*>(static_cast<char*>(packed) + kHStatusOff);
+    if (hipMemsetAsync(status, 0, 16, stream) != hipSuccess) return NRF_ERR_RUNTIME;
     nrf_launch_begin();
     auto launch = [&](XPackLayer p, int step0) {
         p.dst = base + int64_t(step0) * (kHStepBytes / 2);
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
-        hpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+        hpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p, status);
     };
     xpack_forward_layers(w, launch);
     const PackSmall s = xpack_small(w, b, packed, kHSmallFloatOff);
     pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
     return nrf_launch_status();
+}
+
+// NRF_OK, or NRF_ERR_RANGE when the packer met a weight outside fp16's range (the forward kernels then return NaN).
+// Waits for the stream.
+NRF_EXPORT int nrf_packed_fp16x2_status(const void* packed, nrf_stream_t stream_) {
+    if (!packed) return NRF_ERR_NULL;
+    unsigned flag = 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (hipMemcpyAsync(&flag, static_cast<const char*>(packed) + kHStatusOff, 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        return NRF_ERR_RUNTIME;
+    return flag ? NRF_ERR_RANGE : NRF_OK;
 }
 
 NRF_EXPORT int nrf_mlp_forward_rays_fp16x2(const void* packed, const float* rays_o, const float* rays_d, const float* z,

@@ -146,8 +146,10 @@ def mlp_forward_points_bf16x3(packed_x3, pts, dirs) -> torch.Tensor:
     return raw
 
 
-def pack_weights_fp16x2(weights, biases, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Same inputs as pack_weights -> the two-term fp16 streaming layout of nrf_mlp_forward_rays_fp16x2 (uint8 buffer)."""
+def pack_weights_fp16x2(weights, biases, out: torch.Tensor | None = None, check_range: bool = True) -> torch.Tensor:
+    """Same inputs as pack_weights -> the two-term fp16 streaming layout of nrf_mlp_forward_rays_fp16x2 (uint8 buffer).
+    ``check_range`` waits for the packer and raises NrfError when a weight lies outside fp16's range (|w| >= 65520 or
+    not finite); without it such a buffer makes the forward kernels return NaN."""
     assert len(weights) == 12 and len(biases) == 12
     ws = [_f32(w.detach(), "weight") for w in weights]
     bs = [_f32(b.detach(), "bias") for b in biases]
@@ -161,13 +163,16 @@ def pack_weights_fp16x2(weights, biases, out: torch.Tensor | None = None) -> tor
     bp = (C.c_void_p * 12)(*[b.data_ptr() for b in bs])
     with torch.cuda.device(dev):
         check(lib().nrf_pack_weights_fp16x2(wp, bp, _ptr(out), _stream(out)), "nrf_pack_weights_fp16x2")
+    if check_range:
+        with torch.cuda.device(dev):
+            check(lib().nrf_packed_fp16x2_status(_ptr(out), _stream(out)), "nrf_pack_weights_fp16x2")
     return out
 
 
-def pack_state_dict_fp16x2(sd: dict, prefix: str, device) -> torch.Tensor:
+def pack_state_dict_fp16x2(sd: dict, prefix: str, device, check_range: bool = True) -> torch.Tensor:
     ws = [torch.as_tensor(sd[f"{prefix}.{n}.weight"]).to(device=device, dtype=torch.float32) for n in LAYER_NAMES]
     bs = [torch.as_tensor(sd[f"{prefix}.{n}.bias"]).to(device=device, dtype=torch.float32) for n in LAYER_NAMES]
-    return pack_weights_fp16x2(ws, bs)
+    return pack_weights_fp16x2(ws, bs, check_range=check_range)
 
 
 def mlp_forward_rays_fp16x2(packed_h2, rays_o, rays_d, z) -> torch.Tensor:

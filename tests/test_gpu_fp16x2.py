@@ -117,5 +117,30 @@ def test_fp16x2_small_and_large_operands(dev):
     w = sd["model.pts_linears.4.weight"].copy()
     w[3, 5] = 7.0e4                                   # outside fp16: hi term = inf
     big["model.pts_linears.4.weight"] = w
-    out = ops.mlp_forward_points_fp16x2(ops.pack_state_dict_fp16x2(big, "model", dev), pts, dirs)
-    assert not torch.isfinite(out).all()
+    from nerf_amd._lib import NrfError
+    with pytest.raises(NrfError, match="fp16's range"):
+        ops.pack_state_dict_fp16x2(big, "model", dev)
+    out = ops.mlp_forward_points_fp16x2(ops.pack_state_dict_fp16x2(big, "model", dev, check_range=False), pts, dirs)
+    assert torch.isnan(out).all()                     # the kernel refuses the whole network
+    # activations beyond the range poison their own point only: one huge coordinate in a batch of ordinary ones
+    far = pts.clone()
+    far[17, 0] = 1.0e5
+    ph = ops.pack_state_dict_fp16x2(sd, "model", dev)
+    out = ops.mlp_forward_points_fp16x2(ph, far, dirs)
+    ok = torch.ones(far.shape[0], dtype=torch.bool, device=dev)
+    ok[17] = False
+    assert torch.isnan(out[17]).all() and torch.isfinite(out[ok]).all()
+    assert torch.equal(out[ok], ops.mlp_forward_points_fp16x2(ph, pts, dirs)[ok])
+    # ... and so does a hidden activation beyond it (h2 scaled by 2^20 through two layers, undone by the third)
+    hot = dict(sd)
+    f = lambda e: np.float32(2.0 ** e)
+    hot["model.pts_linears.1.weight"] = sd["model.pts_linears.1.weight"] * f(6)
+    hot["model.pts_linears.1.bias"] = sd["model.pts_linears.1.bias"] * f(6)
+    hot["model.pts_linears.2.weight"] = sd["model.pts_linears.2.weight"] * f(14)
+    hot["model.pts_linears.2.bias"] = sd["model.pts_linears.2.bias"] * f(20)
+    hot["model.pts_linears.3.weight"] = sd["model.pts_linears.3.weight"] * f(-20)
+    out = ops.mlp_forward_points_fp16x2(ops.pack_state_dict_fp16x2(hot, "model", dev), pts, dirs)
+    h2 = float(torch.isnan(out).all(-1).float().mean())
+    print(f"hidden activations scaled by 2^20: {h2:.3f} of the points refused (NaN), the rest finite: "
+          f"{bool(torch.isfinite(out[~torch.isnan(out).any(-1)]).all())}")
+    assert h2 > 0.5 and bool((torch.isnan(out).all(-1) | torch.isfinite(out).all(-1)).all())

@@ -7,6 +7,6 @@ cd "$(dirname "$0")/../../nerf_amd/csrc"
 rm -f ../lib/ab_*.so
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 $flags -shared mlp_fp16x2.hip -o ../lib/ab_$name.so 2>&1 | grep -E "error" || true
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -pragma-unroll-threshold=1000000 $flags -shared mlp_fp16x2.hip -o ../lib/ab_$name.so 2>&1 | grep -E "error" || true
 done
 ls ../lib
