@@ -16,20 +16,21 @@ split in contiguous slices over the ranks and one all_gather assembles the frame
 value = rays of the frame / max-over-ranks time per frame (strong scaling, the metric's "ms per
 800x800 frame at 1/2/4/8 MI355X"); the one-view-per-rank rate is carried as `weak_scaling`.
 
-The MLP of the default run is mlp_bf16x3_kernel: fp32 in, fp32 out, fp32 accumulate, each fp32 operand carried as
-three bf16 terms and each product as six bf16 MFMAs (every term down to 2^-24 of the product is kept).  Its distance
-to float64 is that of the fp32 kernel (1.0-1.35x on the fixtures), it holds the 1e-4 bar on every fixture and the
-full-frame spot check, and `dtype` names it; `--dtype fp32` runs the fp32 MFMA kernel, and the default line carries
-that frame as `also.fp32_frame`.
+The MLP of the default run is mlp_fp16x2_kernel: fp32 in, fp32 out, fp32 accumulate, each fp32 operand carried as two
+fp16 terms (22 significand bits) and each product as three fp16 MFMAs.  Its distance to float64 is the fp32 reference's
+own on every fixture (0.8-1.1x: an fp32 accumulation of 256 terms loses more than the 2^-22 operand error), it holds
+the 1e-4 bar on every fixture and the full-frame spot check, and `dtype` names it.  `--dtype bf16x3` carries every
+operand exactly (three bf16 terms, six MFMAs per product), `--dtype fp32` runs the fp32 MFMA kernel; the default line
+carries both frames as `also.bf16x3_frame` and `also.fp32_frame`.
 
 The same JSON line carries
   roofline      the dominant kernel (MFMA-bound): algorithmic FLOPs of the fp32 problem per launch
                 / its mean launch time, measured with HIP events on the launch stream inside
-                the timed region; peak = bf16 MFMA 2500 / 6 TFLOP/s for bf16x3 (six MFMAs per product),
-                fp32 MFMA 157.3 TFLOP/s for --dtype fp32 (MI355X_MICROARCH.md)
+                the timed region; peak = fp16 MFMA 2500 / 3 TFLOP/s for fp16x2 (three MFMAs per product), bf16 MFMA
+                2500 / 6 for bf16x3 (six), fp32 MFMA 157.3 TFLOP/s for --dtype fp32 (MI355X_MICROARCH.md)
   cpu_baseline  oracle/ (the CPU restatement of the reference) timed on this host's cores
                 on a bounded sample of the same rays (rank 0, N=1 only)
-  also          (N=1) the fp32 MFMA frame, BASELINE configs[4] per-view form (bf16 MLP), configs[2] (training step)
+  also          (N=1) the bf16x3 and fp32 MFMA frames, BASELINE configs[4] per-view form (bf16 MLP), configs[2] (training step)
                 and configs[3] (KiloNeRF frame), measured in the same process after the headline.
 """
 import argparse
@@ -51,6 +52,17 @@ FLOP_PER_POINT = 2 * MACS_PER_POINT
 FP32_MFMA_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0
+DEFAULT_DTYPE = "fp16x2"
+# MFMA ceiling on the FLOPs of the fp32 problem: the fp16 / bf16 matrix peak divided by the MFMAs one fp32 product takes
+PEAK_TFLOPS = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 6,
+               "fp16x2": BF16_MFMA_PEAK_TFLOPS / 3}   # MI355X_MICROARCH.md: fp16 and bf16 dense MFMA peaks are equal
+DTYPE_LABEL = {"fp32": "f32", "bf16": "bf16",
+               "bf16x3": "bf16x3 (f32 operands as 3 bf16 terms, f32 accumulate; f32 elsewhere)",
+               "fp16x2": "fp16x2 (f32 operands as 2 fp16 terms = 22 significand bits, f32 accumulate; f32 elsewhere)"}
+MLP_KERNEL = {"fp32": "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
+              "bf16": "mlp_bf16_kernel (fused points + PE + 8x256 MLP, bf16 MFMA)",
+              "bf16x3": "mlp_bf16x3_kernel (fused points + PE + 8x256 MLP, 6 bf16 MFMAs per fp32 product; peak = bf16 peak / 6)",
+              "fp16x2": "mlp_fp16x2_kernel (fused points + PE + 8x256 MLP, 3 fp16 MFMAs per fp32 product; peak = fp16 peak / 3)"}
 
 
 def parse(argv=None):
@@ -70,12 +82,14 @@ def parse(argv=None):
                          "(strong scaling; a step = one pass over all views, a warm-up step = one view per rank; use with "
                          "--dtype bf16); frame: the ray-sharded headline of `render` alone, without per-stage events")
     ap.add_argument("--views", type=int, default=200, help="testset mode: number of views in the set")
-    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "fp32", "bf16"],
-                    help="render mode only: bf16x3 (default) = BASELINE configs[1], the fp32 computation with every MLP "
-                         "operand carried as three bf16 terms on the bf16 MFMA (fp32-class: as close to float64 as the fp32 "
-                         "kernel and inside the 1e-4 bar on every fixture and the full frame, tests/test_gpu_bf16x3.py, "
-                         "tests/test_gpu_fullsize.py), `dtype` says so; fp32 = the same on the fp32 MFMA kernel; bf16 = the "
-                         "bf16 MLP of configs[4], reported under its own metric name")
+    ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["fp16x2", "bf16x3", "fp32", "bf16"],
+                    help="render mode only: fp16x2 (default) = BASELINE configs[1], the fp32 computation with every MLP "
+                         "operand carried as two fp16 terms (22 significand bits) on the fp16 MFMA, three MFMAs per product, "
+                         "fp32 accumulate (fp32-class: as close to float64 as the fp32 reference and inside the 1e-4 bar on "
+                         "every fixture and the full frame, tests/test_gpu_fp16x2.py, tests/test_gpu_fullsize.py), `dtype` "
+                         "says so; bf16x3 = three bf16 terms (all 24 bits), six MFMAs per product; fp32 = the fp32 MFMA "
+                         "kernel; bf16 = the bf16 MLP of configs[4], reported under its own metric name.  --mode train runs "
+                         "its matrix work on the bf16x3 kernels unless --dtype fp32")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -91,7 +105,7 @@ def recorded_traffic(dtype: str = "fp32"):
     (mlp_bf16x3_kernel) or r02_bf16_traffic_pmc.json (mlp_bf16_kernel); tools/run_bench_traffic.sh collects them.
     Counters cannot be read from inside the process, so this is the recorded figure, or None when the file is absent."""
     path = os.path.join(ROOT, "profiles", {"fp32": "r01_mlp_traffic_pmc.json", "bf16x3": "r02_bf16x3_traffic_pmc.json",
-                                           "bf16": "r02_bf16_traffic_pmc.json"}[dtype])
+                                           "bf16": "r02_bf16_traffic_pmc.json", "fp16x2": "r02_fp16x2_traffic_pmc.json"}[dtype])
     try:
         with open(path) as f:
             return float(json.load(f)["traffic_bytes_per_launch_mean"])
@@ -147,8 +161,8 @@ def parity_check(sd, o, d, kept, dev, dtype="fp32"):
     from nerf_amd import ops
     from nerf_amd.renderer import near_far_table
     bins = torch.from_numpy(near_far_table(2.0, 6.0, N_COARSE)).to(dev)
-    pack = ops.pack_state_dict_bf16x3 if dtype == "bf16x3" else ops.pack_state_dict
-    mlp = ops.mlp_forward_rays_bf16x3 if dtype == "bf16x3" else ops.mlp_forward_rays
+    pack = {"bf16x3": ops.pack_state_dict_bf16x3, "fp16x2": ops.pack_state_dict_fp16x2}.get(dtype, ops.pack_state_dict)
+    mlp = {"bf16x3": ops.mlp_forward_rays_bf16x3, "fp16x2": ops.mlp_forward_rays_fp16x2}.get(dtype, ops.mlp_forward_rays)
     pc, pf = pack(sd, "model", dev), pack(sd, "model_fine", dev)
     flips = samples = 0
     err = {"fine_rgb_map": 0.0, "fine_depth_map": 0.0, "alpha_map": 0.0}
@@ -211,7 +225,7 @@ def train_bench(args, net, dev, rank, world, dist):
     # --dtype bf16x3 (the default): the step's matrix work (two forward passes, the backward's data-gradient chain, the
     # weight-gradient GEMMs) on the three-term bf16 kernels (fp32-class, same saved activations); the alpha / rgb head
     # rows stay on the fp32 MFMA / VALU.  --dtype fp32: everything on the fp32 MFMA.
-    x3 = args.dtype == "bf16x3"
+    x3 = args.dtype in ("bf16x3", "fp16x2")     # fp16x2 is a render kernel: the training step's split kernels are bf16x3
     ts = TrainStep(net, dev, forward_dtype="bf16x3" if x3 else "fp32")
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
@@ -558,16 +572,16 @@ def testset_bench(args, net, dev, rank, world, dist):
         elapsed = float(t.item())
     assert torch.isfinite(out["fine_rgb_map"]).all()
     if rank == 0:
-        bf16, x3 = args.dtype == "bf16", args.dtype == "bf16x3"
+        bf16 = args.dtype == "bf16"
         flop = float(len(poses)) * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
-        peak = (BF16_MFMA_PEAK_TFLOPS if bf16 else BF16_MFMA_PEAK_TFLOPS / 6 if x3 else FP32_MFMA_PEAK_TFLOPS) * world
+        peak = PEAK_TFLOPS[args.dtype] * world
         achieved = flop * args.steps / elapsed / 1e12
         line = {
             "metric": "rays/sec (%d-view test set, 800x800, 64 coarse + 128 fine samples/ray%s)" % (len(poses), ", bf16 MLP" if bf16 else ""),
             "value": len(poses) * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_frame": 1e3 * elapsed / args.steps / len(poses),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16" if bf16 else "bf16x3" if x3 else "f32",
+            "dtype": DTYPE_LABEL[args.dtype],
             "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
             "config": {"workload": "BASELINE configs[4]: %d-view test-set render, views dealt round-robin over %d rank(s), %s MLP"
                                    % (len(poses), world, args.dtype), "views": len(poses), "rays_per_frame": R,
@@ -594,9 +608,10 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     renderer = Renderer(net, default_cfg(perturb=0), mlp_dtype=dtype)
-    bf16, x3 = dtype == "bf16", dtype == "bf16x3"
-    # bf16x3: six bf16 MFMAs stand for one fp32 product, so the ceiling on the FLOPs of the fp32 problem is peak / 6
-    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else BF16_MFMA_PEAK_TFLOPS / 6 if x3 else FP32_MFMA_PEAK_TFLOPS
+    bf16, x3, h2 = dtype == "bf16", dtype == "bf16x3", dtype == "fp16x2"
+    # bf16x3 / fp16x2: six / three MFMAs stand for one fp32 product, so the ceiling on the FLOPs of the fp32 problem is
+    # the matrix peak / 6 or / 3
+    peak = PEAK_TFLOPS[dtype]
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
     R = H * W
@@ -668,12 +683,15 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
         "higher_is_better": True,
         "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None,
-        "dtype": "bf16" if bf16 else "bf16x3 (f32 operands as 3 bf16 terms, f32 accumulate; f32 elsewhere)" if x3 else "f32",
+        "dtype": DTYPE_LABEL[dtype],
         "data": "synthetic (orbit camera, random-init weights, alpha_linear x30 + 2)",
         "config": {"workload": ("BASELINE configs[4] per-view form: full 800x800 test-view render, NeRF coarse+fine, bf16 MLP "
                                 "(bf16 weights + activations, fp32 accumulate), " if bf16 else
                                 "BASELINE configs[1] with the MLP's fp32 operands carried as three bf16 terms each (six bf16 "
                                 "MFMAs per product, fp32 accumulate; fp32 in, fp32 out, fp32 everywhere else), " if x3 else
+                                "BASELINE configs[1] with the MLP's fp32 operands carried as two fp16 terms each (22 significand "
+                                "bits, three fp16 MFMAs per product, fp32 accumulate; fp32 in, fp32 out, fp32 everywhere "
+                                "else), " if h2 else
                                 "BASELINE configs[1]: full 800x800 lego test-view render, NeRF coarse+fine, fp32, ") +
                                ("one view per step on one GPU" if world == 1 else
                                 "one view per step, its rays in contiguous slices over %d ranks, outputs all-gathered on "
@@ -696,9 +714,7 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
         cmp_bytes = mine * ((N_COARSE + N_IMPORTANCE) * 20 + 20)
         whole = world == 1
         line["roofline"] = {
-            "kernel": "mlp_bf16_kernel (fused points + PE + 8x256 MLP, bf16 MFMA)" if bf16 else
-                      "mlp_bf16x3_kernel (fused points + PE + 8x256 MLP, 6 bf16 MFMAs per fp32 product; peak = bf16 peak / 6)"
-                      if x3 else "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
+            "kernel": MLP_KERNEL[dtype],
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": recorded_traffic(dtype) if whole else None,
             "traffic_note": "HBM bytes per launch (mean of coarse + fine) from the committed rocprofv3 PMC passes of this "
@@ -737,9 +753,10 @@ def also_block(args, net, dev):
     sub = argparse.Namespace(**vars(args))
     sub.no_cpu_baseline = True
     out = {}
-    other = "fp32" if args.dtype == "bf16x3" else "bf16x3"    # the headline's other fp32-class kernel, same view sequence
-    out[other + "_frame"] = cut(render_bench(sub, net, dev, 0, 1, None, dtype=other, steps=3, warmup=1, cpu=False))
-    torch.cuda.empty_cache()
+    for other in ("fp16x2", "bf16x3", "fp32"):     # the headline's other fp32-class kernels, same view sequence
+        if other != args.dtype:
+            out[other + "_frame"] = cut(render_bench(sub, net, dev, 0, 1, None, dtype=other, steps=3, warmup=1, cpu=False))
+            torch.cuda.empty_cache()
     out["bf16_frame"] = cut(render_bench(sub, net, dev, 0, 1, None, dtype="bf16", steps=5, warmup=1, cpu=False))
     torch.cuda.empty_cache()
     sub.steps, sub.warmup = 20, 3

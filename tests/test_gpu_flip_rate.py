@@ -16,7 +16,8 @@ R, NC, NI = 4096, 64, 128
 FLIP_BOUND = 2e-4          # stated bound on flips / samples (measured: see the printed report)
 
 
-def test_end_to_end_index_flip_rate():
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3", "fp16x2"])
+def test_end_to_end_index_flip_rate(dtype):
     from nerf_amd import ops
     from nerf_amd.camera import focal_from_angle, pose_spherical
     from nerf_amd.renderer import near_far_table
@@ -31,7 +32,9 @@ def test_end_to_end_index_flip_rate():
     table = near_far_table(2.0, 6.0, NC)
     bins = torch.from_numpy(table).to(dev)
 
-    raw = ops.mlp_forward_rays(ops.pack_state_dict(sd, "model", dev), rays_o, rays_d, bins)
+    pack = {"fp32": ops.pack_state_dict, "bf16x3": ops.pack_state_dict_bf16x3, "fp16x2": ops.pack_state_dict_fp16x2}[dtype]
+    mlp = {"fp32": ops.mlp_forward_rays, "bf16x3": ops.mlp_forward_rays_bf16x3, "fp16x2": ops.mlp_forward_rays_fp16x2}[dtype]
+    raw = mlp(pack(sd, "model", dev), rays_o, rays_d, bins)
     _, _, w, _ = ops.composite(raw, bins, True, True)
     z, fine, idx = ops.sample_fine(w, bins, bins, u.to(dev), u2.to(dev), want_debug=True)
     with torch.no_grad():
@@ -43,7 +46,7 @@ def test_end_to_end_index_flip_rate():
     n_flip, total = int(flipped.sum()), idx.size
     dz = np.abs(fine - ref_fine)
     w_err = float(np.abs(w.cpu().numpy() - ref["w_coarse"].numpy()).max())
-    print(f"flip report: {n_flip} of {total} fine-sample indices differ ({n_flip / total:.2e}); rays touched "
+    print(f"flip report ({dtype} MLP): {n_flip} of {total} fine-sample indices differ ({n_flip / total:.2e}); rays touched "
           f"{int(flipped.any(1).sum())} of {R}; max |dz| of flipped samples {float(dz[flipped].max()) if n_flip else 0.0:.4f} "
           f"(one bin = {4 / 63:.4f}); max |w_hip - w_oracle| = {w_err:.2e}")
     assert n_flip / total <= FLIP_BOUND

@@ -217,9 +217,10 @@ def test_bf16_full_frame_oracle_spot_check(frame_bf16):
         assert e16 < tol, (k, e16)
 
 
-# ---- bf16x3 MLP at full size: the fp32 headline's kernel (three-term bf16 operands, fp32-class) -------------------------
-@pytest.fixture(scope="module")
-def frame_x3(dev):
+# ---- the split-operand MLPs at full size: the fp32 headline's kernels (bf16x3: three bf16 terms per operand; fp16x2: two
+# fp16 terms; both fp32-class) ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="module", params=["bf16x3", "fp16x2"])
+def frame_x3(dev, request):
     from nerf_amd import ops
     from nerf_amd.camera import focal_from_angle, test_set_poses
     from nerf_amd.config import default_cfg
@@ -228,7 +229,7 @@ def frame_x3(dev):
     from nerf_amd.weights import make_state_dict
     net = Network()
     net.load_state_dict(make_state_dict(0, 30.0, 2.0))
-    r = Renderer(net.to(dev), default_cfg(perturb=0), mlp_dtype="bf16x3")
+    r = Renderer(net.to(dev), default_cfg(perturb=0), mlp_dtype=request.param)
     o, d = ops.raygen(test_set_poses(200)[3], H, W, focal_from_angle(W), dev)      # the fp32 frame's view and uniforms
     g = torch.Generator(device=dev).manual_seed(7)
     u = torch.rand((H * W, 128), device=dev, generator=g)
@@ -267,7 +268,7 @@ def test_x3_full_frame_oracle_spot_check(frame_x3):
         want = ref[k].numpy()
         got = out[k][di].cpu().numpy().reshape(want.shape)
         err = float(np.abs(got - want).max())
-        print(f"bf16x3 frame spot check {k}: {err:.2e}")
+        print(f"{r.mlp_dtype} frame spot check {k}: {err:.2e}")
         assert err < 1e-4, (k, err)
 
 
@@ -280,6 +281,6 @@ def test_x3_frame_against_the_fp32_frame(frame, frame_x3):
         diff = (out32[k].reshape(H * W, -1) - out3[k].reshape(H * W, -1)).abs().amax(1)
         worst[k] = float(diff.max())
         frac = float((diff > 1e-4).float().mean())
-        print(f"bf16x3 vs fp32 frame {k}: max {worst[k]:.2e}, rays over 1e-4: {frac:.2e}")
+        print(f"{frame_x3[0].mlp_dtype} vs fp32 frame {k}: max {worst[k]:.2e}, rays over 1e-4: {frac:.2e}")
         assert frac < 2e-4, (k, frac)
     assert worst["coarse_rgb_map"] < 1e-4 and worst["coarse_depth_map"] < 1e-4     # no resampling before the coarse maps
