@@ -540,7 +540,7 @@ NRF_EXPORT int nrf_pack_weights_transposed_bf16x3(const float* const* w, void* p
     nrf_launch_begin();
     int step = 0;
     auto launch = [&](const float* W, int ldw, int in_blocks, int col0) {   // in_blocks = k-blocks = rows of W / 32
-        XPackLayer p{W, base + int64_t(step) * (kXStepBytes / 2), ldw, 8, 0, in_blocks, 0, 0, 0, 0, col0, 0, 1, 1};
+        XPackLayer p{W, base + int64_t(step) * (kXStepBytes / 2), ldw, 8, 0, in_blocks, 0, 0, 0, 0, col0, 0, 2, 1};
         const int total = 8 * in_blocks * 2 * 512;
         xpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
         step += 8 * in_blocks * 2;

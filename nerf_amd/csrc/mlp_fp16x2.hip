@@ -33,6 +33,11 @@ constexpr int kHPieces = kHChunkBytes / 1024 / 4;     // LDS-DMA pieces per wave
 #ifndef H2_LOOK
 #define H2_LOOK 2
 #endif
+#ifndef H2_LEAD
+#define H2_LEAD 2
+#endif
+constexpr int kHLead = H2_LEAD;                       // output blocks a hidden-type layer opens with (h2_hidden_layer): 2 or 3,
+                                                      // measured alike (37.4 | 37.7 ms per 65,536 x 192 points, one process)
 constexpr int kHLook = H2_LOOK;                       // LDS -> register look-ahead of the weight fragments, in steps (< 4)
 constexpr int64_t kHSmallFloatOff = int64_t(kXStreamSteps) * kHStepBytes / 4;   // fp32 small block behind the stream
 constexpr int64_t kHStatusOff = kHSmallFloatOff * 4 + int64_t(kSmallFloats) * 4;   // bytes: one status word behind the small block
@@ -256,17 +261,19 @@ __device__ __forceinline__ void h2_pe_layer(HRing& st, int lane, const float* bi
 }
 
 // Hidden-type layer: Y[ob] = bias + W . [X (NHID k-blocks), post], X[kb] = op(Y[kb] of the previous layer).
-// As in mlp_bf16x3.hip the layer opens with output blocks 0 AND 1 accumulated together (stream order
-// [kb][ob in {0,1}][s2]): X[kb+1] is made in 24 sub-slices, two per MFMA gap, under the 12 MFMAs of k-block kb.  Block 1
-// accumulates into the spare block Z because the previous layer's Y[1] is still needed (it becomes X[1] during
-// k-block 0).  Second accumulators: YL[0] for block 0 (folded in under block 1's last two steps), YL[1] for block 1
-// (folded in under block 2, together with the move Z -> Y[1]), then YL[ob & 1], each folded in under the next block;
-// the last block's fold-in is the only one that waits for its MFMAs.
-template <int NOB, int NPOST, int MODE, int NHID = 8>
+// Making one X[kb] costs about as much VALU time as twelve MFMAs give, so the layer opens with its first LEAD output
+// blocks accumulated together (stream order [kb][ob < LEAD][s2]): X[kb+1] is made in 24 sub-slices spread over the
+// 6 LEAD MFMA gaps of k-block kb.  Blocks 1 .. LEAD-1 accumulate into the spare blocks Z because the previous layer's
+// Y[1 ..] are still needed (Y[b] becomes X[b] during k-block b - 1).  Second accumulators: YL[b] for lead block b --
+// block 0's is folded in under the last lead steps, the others' under the first block after the lead, together with the
+// moves Z -> Y -- then two of them in turn, each folded in under the next block; the last block's fold-in is the only
+// one that waits for its MFMAs.
+template <int NOB, int NPOST, int MODE, int NHID = 8, int LEAD = kHLead>
 __device__ __forceinline__ void h2_hidden_layer(HRing& st, int lane, const float* bias_h, u32x4 (*X)[2][2],
-                                                const u32x4 (*post)[2][2], f32x16* Y, f32x16& Z, f32x16* YL, OpInH& op) {
+                                                const u32x4 (*post)[2][2], f32x16* Y, f32x16* Z, f32x16* YL, OpInH& op) {
     constexpr int NKB = NHID + NPOST;
-    static_assert(NOB >= 3, "the fold-in schedule assumes a block after the paired pass");
+    static_assert(LEAD >= 2 && LEAD <= 3 && NOB > LEAD, "the fold-in schedule assumes a block after the lead");
+    static_assert(8 * LEAD - 6 <= 2 * NKB * 3, "block LEAD must have gaps for the lead blocks' fold-ins");
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto bias = [&](int ob) { return MODE == kOpBwd ? zero16 : *reinterpret_cast<const f32x16*>(bias_h + ob * 32); };
     static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
@@ -274,54 +281,62 @@ __device__ __forceinline__ void h2_hidden_layer(HRing& st, int lane, const float
 #pragma unroll
     for (int q = 0; q < 8; ++q) op.template pair<MODE>(Y[0], X[0], 0, q);
     Y[0] = bias(0);
-    Z = bias(1);
+#pragma unroll
+    for (int b = 1; b < LEAD; ++b) Z[b - 1] = bias(b);
+    constexpr int G = 6 * LEAD;   // MFMA gaps per lead k-block
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         const bool make = kb + 1 < NHID;
         if (make) op.begin(kb + 1, Y[kb + 1]);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < LEAD; ++b)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const u32x4* x = kb < NHID ? X[kb][s2] : post[kb - NHID][s2];
-                const int g = b * 2 + s2;                       // which of the k-block's four steps
-                auto hook = [&](int m) {                        // 12 MFMAs: sub-slices 2n and 2n + 1 after MFMA n
+                const int g = b * 2 + s2;                       // which of the k-block's 2 LEAD steps
+                auto hook = [&](int m) {                        // sub-slices [24 n / G, 24 (n + 1) / G) after MFMA n
                     const int n = g * 3 + m;
                     if (make) {
-                        op.template sub<MODE>(Y[kb + 1], X[kb + 1], kb + 1, (2 * n) / 3, (2 * n) % 3);
-                        op.template sub<MODE>(Y[kb + 1], X[kb + 1], kb + 1, (2 * n + 1) / 3, (2 * n + 1) % 3);
+#pragma unroll
+                        for (int w = (24 * n) / G; w < (24 * (n + 1)) / G; ++w)
+                            op.template sub<MODE>(Y[kb + 1], X[kb + 1], kb + 1, w / 3, w % 3);
                     }
                     if (kb == NKB - 1) {
-                        // block 0 finished with step g = 1: its fold-in goes under block 1's last two steps
-                        if (n >= 8) fold_slice(Y[0], Y[0], YL[0], 4 * (n - 8), 4 * (n - 7));
-                        // the next block's bias is read one step ahead of its first MFMA (Y[2] is free: X[2] is made)
-                        if (g == 3 && m == 0) Y[2] = bias(2);
+                        // block 0 finished with step g = 1: its fold-in goes under the other lead blocks' last steps
+                        if (n >= 8 && n < 12) fold_slice(Y[0], Y[0], YL[0], 4 * (n - 8), 4 * (n - 7));
+                        // the next block's bias is read one step ahead of its first MFMA (Y[LEAD] is free: X[LEAD] is made)
+                        if (g == 2 * LEAD - 1 && m == 0) Y[LEAD] = bias(LEAD);
                     }
                 };
-                if (kb == 0 && s2 == 0) h2_step<true>(st, lane, kb * 4 + g, b == 0 ? Y[0] : Z, YL[b], x, hook);
-                else h2_step<false>(st, lane, kb * 4 + g, b == 0 ? Y[0] : Z, YL[b], x, hook);
+                if (kb == 0 && s2 == 0) h2_step<true>(st, lane, kb * 2 * LEAD + g, b == 0 ? Y[0] : Z[b - 1], YL[b], x, hook);
+                else h2_step<false>(st, lane, kb * 2 * LEAD + g, b == 0 ? Y[0] : Z[b - 1], YL[b], x, hook);
             }
     }
+    // second accumulator of a block after the lead: block LEAD takes YL[0] (folded above), then they alternate
+    auto yl_of = [](int ob) { return ob < LEAD ? ob : (ob - LEAD) & 1; };
 #pragma unroll
-    for (int ob = 2; ob < NOB; ++ob) {
+    for (int ob = LEAD; ob < NOB; ++ob) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 auto hook = [&](int m) {
                     const int n = (kb * 2 + s2) * 3 + m;
-                    if (n >= 2 && n < 10) {   // the previous block's fold-in (block 1: out of Z)
-                        if (ob == 2) fold_slice(Y[1], Z, YL[1], 2 * (n - 2), 2 * (n - 1));
-                        else fold_slice(Y[ob - 1], Y[ob - 1], YL[(ob - 1) & 1], 2 * (n - 2), 2 * (n - 1));
+                    if (ob == LEAD) {         // the lead blocks 1 .. LEAD-1: out of Z, eight gaps each
+#pragma unroll
+                        for (int b = 1; b < LEAD; ++b)
+                            if (n >= 8 * b - 6 && n < 8 * b + 2) fold_slice(Y[b], Z[b - 1], YL[b], 2 * (n - 8 * b + 6), 2 * (n - 8 * b + 7));
+                    } else if (n >= 2 && n < 10) {   // the previous block's fold-in
+                        fold_slice(Y[ob - 1], Y[ob - 1], YL[yl_of(ob - 1)], 2 * (n - 2), 2 * (n - 1));
                     }
                     if (kb == NKB - 1 && s2 == 1 && m == 0 && ob + 1 < NOB) Y[ob + 1] = bias(ob + 1);
                 };
                 const u32x4* x = kb < NHID ? X[kb][s2] : post[kb - NHID][s2];
-                if (kb == 0 && s2 == 0) h2_step<true>(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], YL[ob & 1], x, hook);
-                else h2_step<false>(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], YL[ob & 1], x, hook);
+                if (kb == 0 && s2 == 0) h2_step<true>(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], YL[yl_of(ob)], x, hook);
+                else h2_step<false>(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], YL[yl_of(ob)], x, hook);
             }
     }
-    fold_slice(Y[NOB - 1], Y[NOB - 1], YL[(NOB - 1) & 1], 0, 16);
+    fold_slice(Y[NOB - 1], Y[NOB - 1], YL[yl_of(NOB - 1)], 0, 16);
 }
 
 // Persistent, one 4-wave workgroup per CU, one wave per SIMD, a wave's tile = 32 points (mlp_fp32.hip's tiling).
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
         }
 
         u32x4 X[8][2][2];
-        f32x16 Y[8], Z, YL[2];
+        f32x16 Y[8], Z[kHLead - 1], YL[kHLead];
         OpInH op{op_in(kActRelu, cst + (kOffAlphaW - kOffBias) + h * 16), 0.f, 0.f, 0.f, 0.f, 0u, poison};
         track_max(op.ovf, px, py);   // the raw coordinates are operands too (the encoding's sin / cos cannot overflow)
         track_max(op.ovf, pz, pz);
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
         asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
         // feature -> views: no activation (saved as it is, no mask)
         OpInH op_views{op_in(kActNone, nullptr, SAVE ? arow + kActFeat * 32 : nullptr), 0.f, 0.f, 0.f, 0.f, 0u, op.ovf};
-        h2_hidden_layer<4, 1, SAVE ? kOpFwdSave : kOpFwd>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, YL, op_views);   // views_linears.0
+        h2_hidden_layer<4, 1, SAVE ? kOpFwdSave : kOpFwd, 8, kHLead>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, YL, op_views);   // views_linears.0
         float r = 0.f, g = 0.f, b = 0.f;
         {
             const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
@@ -498,7 +513,7 @@ NRF_EXPORT int nrf_pack_weights_fp16x2(const float* const* w, const float* const
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
         hpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p, status);
     };
-    xpack_forward_layers(w, launch);
+    xpack_forward_layers(w, launch, kHLead);
     const PackSmall s = xpack_small(w, b, packed, kHSmallFloatOff);
     pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
     return nrf_launch_status();

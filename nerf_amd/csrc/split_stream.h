@@ -31,7 +31,7 @@ struct XPackLayer {
     int pre_kb, hid_kb, post_kb;
     int pre_L, post_L;
     int pre_col0, hid_col0, post_col0;
-    int pair01;   // hidden-type layers: the stream opens with blocks 0 and 1 interleaved, [kb][ob in {0,1}][s2]
+    int lead;     // hidden-type layers: the stream opens with blocks 0 .. lead-1 interleaved, [kb][ob < lead][s2] (0: plain)
     int transposed;   // backward chain: A = W^T (hidden part only): row = a column of W, k = a row of W
 };
 __device__ __forceinline__ int xpack_total(const XPackLayer& p) { return p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512; }
@@ -39,7 +39,7 @@ __device__ __forceinline__ float xpack_fetch(const XPackLayer& p, int idx, int& 
     const int nkb = p.pre_kb + p.hid_kb + p.post_kb;
     jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
     int s2 = step & 1, kbpos = (step >> 1) % nkb, ob = (step >> 1) / nkb;
-    if (p.pair01 && step < 4 * nkb) kbpos = step >> 2, ob = (step >> 1) & 1;
+    if (p.lead > 1 && step < 2 * p.lead * nkb) kbpos = step / (2 * p.lead), ob = (step >> 1) % p.lead;
     const int h = lane >> 5, t = 8 * s2 + jj;
     const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
     float v = 0.f;
@@ -58,16 +58,16 @@ __device__ __forceinline__ float xpack_fetch(const XPackLayer& p, int idx, int& 
 }
 // the forward stream's layers in stream order (kXLayerStep): launch(layer description, first step)
 template <class Launch>
-inline void xpack_forward_layers(const float* const* w, Launch&& launch) {
+inline void xpack_forward_layers(const float* const* w, Launch&& launch, int lead = 2) {
     launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0}, kXLayerStep[0]);
-    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[l]);
+    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0}, kXLayerStep[l]);
     // network.py:58 cat([input_pts, h]): hidden columns 63..318 as a plain layer, then the PE columns 0..62 accumulate
-    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0, 1, 0}, kXLayerStep[5]);
+    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0,lead, 0}, kXLayerStep[5]);
     launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0}, kXLayerStep[6]);
-    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[7]);
-    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[8]);
-    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 1, 0}, kXLayerStep[9]);      // feature_linear
-    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256, 1, 0}, kXLayerStep[10]);   // views_linears.0
+    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0}, kXLayerStep[7]);
+    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0}, kXLayerStep[8]);
+    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0}, kXLayerStep[9]);      // feature_linear
+    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256,lead, 0}, kXLayerStep[10]);   // views_linears.0
 }
 // the small fp32 block behind a stream (biases, alpha / rgb head rows: pack_small_kernel's layout)
 inline PackSmall xpack_small(const float* const* w, const float* const* b, void* packed, int64_t small_float_off) {
