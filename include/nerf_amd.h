@@ -146,6 +146,11 @@ int nrf_mlp_forward_rays_fp16x2(const void* packed_h2, const float* rays_o, cons
                                 int64_t z_stride, int64_t n_rays, int n_samples, float* raw, nrf_stream_t stream);
 int nrf_mlp_forward_points_fp16x2(const void* packed_h2, const float* pts, const float* dirs, int64_t n_points,
                                   float* raw, nrf_stream_t stream);
+/* nrf_mlp_forward_rays_train on the two-term fp16 kernel: same acts / masks layout and sizes (the fp32 value each operand
+ * split starts from is what is saved), for nrf_mlp_backward / nrf_mlp_backward_bf16x3. */
+int nrf_mlp_forward_rays_train_fp16x2(const void* packed_h2, const float* rays_o, const float* rays_d, const float* z,
+                                      int64_t z_stride, int64_t n_rays, int n_samples, float* raw, float* acts,
+                                      uint32_t* masks, nrf_stream_t stream);
 
 /* nrf_mlp_backward with the data-gradient chain (d h_{l-1} = W_l^T dY_l) on the three-term bf16 kernel; the weight-gradient
  * GEMMs are the same fp32 kernels.  packed: nrf_pack_weights (head rows); packed_t_x3: nrf_pack_weights_transposed_bf16x3

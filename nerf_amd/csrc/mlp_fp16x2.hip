@@ -543,6 +543,19 @@ NRF_EXPORT int nrf_mlp_forward_rays_fp16x2(const void* packed, const float* rays
                      static_cast<hipStream_t>(stream));
 }
 
+NRF_EXPORT int nrf_mlp_forward_rays_train_fp16x2(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                                                 int64_t z_stride, int64_t n_rays, int n_samples, float* raw, float* acts,
+                                                 uint32_t* masks, nrf_stream_t stream) {
+    if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0 || z_stride < 0) return NRF_ERR_SHAPE;
+    if (z_stride != 0 && z_stride < n_samples) return NRF_ERR_SHAPE;
+    if (n_rays == 0) return NRF_OK;
+    if (!packed || !rays_o || !rays_d || !z || !raw || !acts || !masks) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed) || !nrf_aligned16(raw)) return NRF_ERR_ALIGN;
+    if (n_rays > (int64_t(1) << 40) / n_samples) return NRF_ERR_SHAPE;
+    return launch_h2(packed, rays_o, rays_d, z, z_stride, n_samples / 32, 1, n_rays * n_samples, raw,
+                     static_cast<hipStream_t>(stream), acts, masks);
+}
+
 NRF_EXPORT int nrf_mlp_forward_points_fp16x2(const void* packed, const float* pts, const float* dirs, int64_t n_points,
                                              float* raw, nrf_stream_t stream) {
     if (n_points < 0 || n_points > (int64_t(1) << 40)) return NRF_ERR_SHAPE;

@@ -326,7 +326,7 @@ def pack_weights_transposed_bf16x3(weights, out: torch.Tensor | None = None) -> 
 def mlp_forward_rays_train(packed, rays_o, rays_d, z, kind: str = "fp32"):
     """-> (raw (R,S,4), acts, masks): the saved tensors are opaque buffers for mlp_backward.  ``kind``: "fp32"
     (``packed`` from pack_weights) or "bf16x3" (``packed`` from pack_weights_bf16x3: the forward on the three-term
-    bf16 kernel, same saved layout)."""
+    bf16 kernel, same saved layout) or "fp16x2" (pack_weights_fp16x2: the two-term fp16 kernel, same saved layout)."""
     rays_o, rays_d, z = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(z, "z")
     R, S = rays_o.shape[0], z.shape[-1]
     stride = 0 if z.ndim == 1 else S
@@ -335,11 +335,12 @@ def mlp_forward_rays_train(packed, rays_o, rays_d, z, kind: str = "fp32"):
     raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
     acts = torch.empty(max(int(L.nrf_mlp_acts_bytes(R, S)), 4) // 4, dtype=torch.float32, device=dev)
     masks = torch.empty(max(int(L.nrf_mlp_masks_bytes(R, S)), 4) // 4, dtype=torch.int32, device=dev)
-    if kind not in ("fp32", "bf16x3"):
-        raise ValueError(f"kind {kind!r}: expected 'fp32' or 'bf16x3'")
+    if kind not in ("fp32", "bf16x3", "fp16x2"):
+        raise ValueError(f"kind {kind!r}: expected 'fp32', 'bf16x3' or 'fp16x2'")
     if S % 32 != 0:
         raise _lib.NrfError(f"n_samples {S}: the MLP kernels take whole 32-point tiles per ray")
-    fn = L.nrf_mlp_forward_rays_train if kind == "fp32" else L.nrf_mlp_forward_rays_train_bf16x3
+    fn = {"fp32": L.nrf_mlp_forward_rays_train, "bf16x3": L.nrf_mlp_forward_rays_train_bf16x3,
+          "fp16x2": L.nrf_mlp_forward_rays_train_fp16x2}[kind]
     with torch.cuda.device(dev):
         check(fn(_ptr(packed), _ptr(rays_o), _ptr(rays_d), _ptr(z), stride, R, S, _ptr(raw), _ptr(acts), _ptr(masks),
                  _stream(raw)), "nrf_mlp_forward_rays_train" + ("" if kind == "fp32" else "_bf16x3"))

@@ -31,11 +31,14 @@ def exponential_lr(base_lr: float, epoch: int, decay_epochs: int = 500, gamma: f
 class TrainStep:
     def __init__(self, net, device, near=2.0, far=6.0, n_coarse=64, n_importance=128, white_bkgd=True,
                  lr=5e-4, clip_value=40.0, process_group=None, forward_dtype="fp32"):
-        """``forward_dtype``: "fp32" (the fp32 MFMA kernels) or "bf16x3" -- the chain kernels (both forward passes and
-        the backward's data-gradient chain) on the three-term bf16 kernel (fp32-class: DESIGN 3.7); the forward saves
-        the same activations, and the weight-gradient GEMMs stay on the fp32 MFMA."""
-        if forward_dtype not in ("fp32", "bf16x3"):
-            raise ValueError(f"forward_dtype {forward_dtype!r}: expected 'fp32' or 'bf16x3'")
+        """``forward_dtype``: "fp32" (the fp32 MFMA kernels), "bf16x3" -- both forward passes, the backward's
+        data-gradient chain and the weight-gradient GEMMs on the three-term bf16 kernels (fp32-class: DESIGN 3.7; the
+        forward saves the same activations) -- or "fp16x2": the two forward passes on the two-term fp16 kernel
+        (same saved activations), the backward as in "bf16x3" (gradients would need a loss scale to sit
+        in fp16's range; bf16's exponent is fp32's)."""
+        if forward_dtype not in ("fp32", "bf16x3", "fp16x2"):
+            raise ValueError(f"forward_dtype {forward_dtype!r}: expected 'fp32', 'bf16x3' or 'fp16x2'")
+        self.backward_dtype = "fp32" if forward_dtype == "fp32" else "bf16x3"
         self.forward_dtype = forward_dtype
         self.net = net
         self.device = torch.device(device)
@@ -78,6 +81,9 @@ class TrainStep:
             self._packed[k] = ops.pack_weights(ws, bs, out=self._packed[k])
             if self.forward_dtype == "bf16x3":
                 self._packed_x3[k] = ops.pack_weights_bf16x3(ws, bs, out=self._packed_x3[k])
+            elif self.forward_dtype == "fp16x2":   # no range check here (it waits for the stream): a weight beyond fp16
+                self._packed_x3[k] = ops.pack_weights_fp16x2(ws, bs, out=self._packed_x3[k], check_range=False)  # -> NaN loss
+            if self.backward_dtype == "bf16x3":
                 self._packed_t[k] = ops.pack_weights_transposed_bf16x3(ws, out=self._packed_t[k])
             else:
                 self._packed_t[k] = ops.pack_weights_transposed(ws, out=self._packed_t[k])
@@ -89,8 +95,7 @@ class TrainStep:
         pc, pf = self._packed
         pc_t, pf_t = self._packed_t
         zc = self.bins if u_coarse is None else ops.perturb_samples(self.bins, u_coarse)
-        x3 = self.forward_dtype == "bf16x3"
-        fc, ff = self._packed_x3 if x3 else (pc, pf)
+        fc, ff = (pc, pf) if self.forward_dtype == "fp32" else self._packed_x3
         raw_c, acts_c, masks_c = ops.mlp_forward_rays_train(fc, rays_o, rays_d, zc, self.forward_dtype)
         c_rgb, c_depth, w_c, _ = ops.composite(raw_c, zc, self.white, True)
         z_f = ops.sample_fine(w_c, self.bins, zc, u, u2, u_fine)
@@ -103,10 +108,10 @@ class TrainStep:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         g_raw_c = ops.composite_backward(raw_c, zc, self.white, g_c)
-        ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, self._ws, out=self.grad[:n], kind=self.forward_dtype)
+        ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, self._ws, out=self.grad[:n], kind=self.backward_dtype)
         del g_raw_c, acts_c, masks_c, raw_c
         g_raw_f = ops.composite_backward(raw_f, z_f, self.white, g_f)
-        ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, self._ws, out=self.grad[n:], kind=self.forward_dtype)
+        ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, self._ws, out=self.grad[n:], kind=self.backward_dtype)
         return {"coarse_rgb_map": c_rgb, "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc}
 
     def step(self, rays_o, rays_d, gt, u, u2, u_coarse=None, u_fine=None):

@@ -86,9 +86,10 @@ def _named_flat(ts):
     return out
 
 
-@pytest.mark.parametrize("forward_dtype", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("forward_dtype", ["fp32", "bf16x3", "fp16x2"])
 def test_gradients_of_4096_rays_match_oracle_autograd(case, forward_dtype):
-    """(bf16x3: the two forward passes on the three-term bf16 kernel, the backward kernels unchanged -- same bars.)"""
+    """(bf16x3: forward passes, data-gradient chain and weight-gradient GEMMs on the three-term bf16 kernels; fp16x2: the
+    forward passes on the two-term fp16 kernel, the backward as bf16x3 -- same bars.)"""
     net, ts, args = _train_step(case, forward_dtype=forward_dtype)
     ts.forward_backward(*args)
     assert abs(float(ts.loss) - case["loss"]) < 1e-5, (float(ts.loss), case["loss"])
@@ -109,7 +110,7 @@ def test_gradients_of_4096_rays_match_oracle_autograd(case, forward_dtype):
         # products, nearly the same order, so its error against the oracle is far below fp32 summation noise), an absolute
         # floor: 3e-10 = 3 % of Adam's eps (1e-8), below which no update can change.  It is needed by one tensor,
         # model_fine.alpha_linear.weight, whose 786 k-term sums cancel to 2e-7 (measured error 6.7e-11).
-        ok = err <= 2e-4 * scale or e_hip64 <= 3 * e_ref64 or (forward_dtype == "bf16x3" and e_hip64 <= 3e-10)
+        ok = err <= 2e-4 * scale or e_hip64 <= 3 * e_ref64 or (forward_dtype != "fp32" and e_hip64 <= 3e-10)
         rows.append((err / scale, name, scale, e_hip64 / scale, e_ref64 / scale))
         if not ok:
             bad.append(rows[-1])
@@ -188,8 +189,9 @@ def test_hip_and_oracle_fine_samples_at_4096_rays(case):
     assert (z[:, 1:] >= z[:, :-1]).all()
 
 
-def test_bf16x3_training_forward_saves_what_the_fp32_forward_saves(case):
-    """nrf_mlp_forward_rays_train_bf16x3 against nrf_mlp_forward_rays_train on 512 rays x 192 samples: raw outputs and
+@pytest.mark.parametrize("kind", ["bf16x3", "fp16x2"])
+def test_split_training_forward_saves_what_the_fp32_forward_saves(case, kind):
+    """nrf_mlp_forward_rays_train_bf16x3 / _fp16x2 against nrf_mlp_forward_rays_train on 512 rays x 192 samples: raw outputs and
     every saved activation row agree to fp32 rounding (both are fp32-class evaluations of the same network), and the
     relu sign words differ only where an activation sits within rounding of zero."""
     from nerf_amd import ops
@@ -200,7 +202,8 @@ def test_bf16x3_training_forward_saves_what_the_fp32_forward_saves(case):
     o, d = case["inp"]["rays_o"][:512].contiguous(), case["inp"]["rays_d"][:512].contiguous()
     z = case["z_fine"][:512].to(dev).contiguous()
     raw32, acts32, m32 = ops.mlp_forward_rays_train(ops.pack_weights(ws, bs), o, d, z)
-    raw3, acts3, m3 = ops.mlp_forward_rays_train(ops.pack_weights_bf16x3(ws, bs), o, d, z, "bf16x3")
+    pack = ops.pack_weights_bf16x3 if kind == "bf16x3" else ops.pack_weights_fp16x2
+    raw3, acts3, m3 = ops.mlp_forward_rays_train(pack(ws, bs), o, d, z, kind)
     assert acts3.shape == acts32.shape and m3.shape == m32.shape
     scale = float(raw32.abs().max())
     assert float((raw3 - raw32).abs().max()) <= 2e-5 * max(1.0, scale)
@@ -209,7 +212,7 @@ def test_bf16x3_training_forward_saves_what_the_fp32_forward_saves(case):
     flips = (m3 ^ m32).view(-1, 9, 4, 64)
     flips = torch.cat([flips[:, :8].reshape(-1), flips[:, 8, :2].reshape(-1)])
     n_flip = int(sum(((flips >> b) & 1).sum() for b in range(32)))
-    print(f"relu sign flips: {n_flip} of {flips.numel() * 32}")
+    print(f"{kind} relu sign flips: {n_flip} of {flips.numel() * 32}")
     assert n_flip <= 1e-5 * flips.numel() * 32
 
 
