@@ -54,9 +54,12 @@ class _RenderTrainFn(torch.autograd.Function):
         white = renderer.white_bkgd > 0
         # mlp_dtype "bf16x3": both forward passes, the data-gradient chain and the weight-gradient GEMMs on the three-term
         # bf16 kernels (fp32-class); the fp32 pack still supplies the head rows of the backward
+        # "fp16x2": the forward passes on the two-term fp16 kernel, the backward as "bf16x3" (bf16 has fp32's
+        # exponent range: gradients need no loss scale)
         kind = renderer.mlp_dtype
-        pc, pc_t = renderer._packed_model("model", dev), renderer._packed_model_t("model", dev, kind)
-        pf, pf_t = renderer._packed_model("model_fine", dev), renderer._packed_model_t("model_fine", dev, kind)
+        bkind = "fp32" if kind == "fp32" else "bf16x3"
+        pc, pc_t = renderer._packed_model("model", dev), renderer._packed_model_t("model", dev, bkind)
+        pf, pf_t = renderer._packed_model("model_fine", dev), renderer._packed_model_t("model_fine", dev, bkind)
         fc = pc if kind == "fp32" else renderer._packed_model("model", dev, kind)
         ff = pf if kind == "fp32" else renderer._packed_model("model_fine", dev, kind)
         zc = bins if u_coarse is None else ops.perturb_samples(bins, u_coarse)
@@ -65,7 +68,7 @@ class _RenderTrainFn(torch.autograd.Function):
         z_f = ops.sample_fine(w_c, bins, zc, u, u2, u_fine)      # integer bins + constants: no gradient
         raw_f, acts_f, masks_f = ops.mlp_forward_rays_train(ff, rays_o, rays_d, z_f, kind)
         f_rgb, f_depth, _, f_acc = ops.composite(raw_f, z_f, white, False)
-        ctx.renderer, ctx.white, ctx.kind = renderer, white, kind
+        ctx.renderer, ctx.white, ctx.kind = renderer, white, bkind
         # pc / pf / pc_t / pf_t are the renderer's cached packed buffers, rewritten in place by the next repack: they
         # are the forward's weights only while no parameter changes before backward
         ctx.params, ctx.versions = params, tuple(p._version for p in params)
@@ -95,8 +98,9 @@ class _RenderTrainFn(torch.autograd.Function):
 class Renderer(nn.Module):
     """``mlp_dtype``: "fp32" (default, the reference's precision), "bf16x3" (fp32-class results from three-term bf16
     operand splits on the bf16 matrix cores), "fp16x2" (fp32-class results from two-term fp16 operand splits, 22-bit
-    operands, for networks whose weights and activations lie in fp16's range; inference only) or "bf16" (BASELINE configs[4]: the MLP on the bf16
-    matrix cores, inference only -- training runs with "fp32" or "bf16x3"; ``cfg.task_arg.mlp_dtype`` is read when the
+    operands, for networks whose weights and activations lie in fp16's range; under autograd its backward runs on the
+    bf16x3 kernels) or "bf16" (BASELINE configs[4]: the MLP on the bf16
+    matrix cores, inference only -- training runs with "fp32", "bf16x3" or "fp16x2"; ``cfg.task_arg.mlp_dtype`` is read when the
     argument is None)."""
 
     def __init__(self, net, cfg=None, mlp_dtype: str | None = None):
@@ -307,8 +311,9 @@ class Renderer(nn.Module):
         u2 = torch.rand(R, ni, device=dev)
         u_fine = torch.rand((R, ni), dtype=torch.float32, device=dev) if perturbed else None
         if needs_grad:
-            if self.mlp_dtype in ("bf16", "fp16x2"):
-                raise NrfError("training runs the fp32-class kernels: construct the Renderer with mlp_dtype='fp32' or 'bf16x3'")
+            if self.mlp_dtype == "bf16":
+                raise NrfError("training runs the fp32-class kernels: construct the Renderer with mlp_dtype='fp32', 'bf16x3' "
+                               "or 'fp16x2'")
             return self.render_rays_train(rays_o, rays_d, u, u2, u_coarse, u_fine)
         return self.render_rays(rays_o, rays_d, u, u2, u_coarse, u_fine)
 

@@ -50,7 +50,7 @@ def _setup(fx, dev, mlp_dtype="fp32"):
     return net, r
 
 
-@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3", "fp16x2"])
 def test_training_step_gradients_match_reference(golden, dev, mlp_dtype):
     """Gradients of the REFERENCE's own training step (tests/golden/train_camera32.npz: autograd through the real
     reference renderer) through Renderer's autograd route -- on the fp32 MFMA kernels and on the three-term bf16 kernels
