@@ -341,7 +341,8 @@ def kilo_bench(args, dev, rank, world, dist):
     net.to(dev)
     c = (torch.arange(256, device=dev, dtype=torch.float32) + 0.5) / 256 * 2 - 1
     occ = ((c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2).sqrt() < 0.75).to(torch.uint8)
-    r = KiloRenderer(net, default_kilo_cfg(), occ)
+    kind = "fp32" if args.dtype == "fp32" else "fp16x2"      # the default --dtype: the tiny MLPs on the fp16 matrix cores
+    r = KiloRenderer(net, default_kilo_cfg(), occ, mlp_dtype=kind)
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
     R = H * W
@@ -361,7 +362,7 @@ def kilo_bench(args, dev, rank, world, dist):
         e0 = E()
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(rays_o, rays_d, r.occ_grid, aabb, r.near, r.far, r.step)
         e1 = E()
-        raw = kilo_ops.kilo_forward(packed, net.num_models, aabb, res, pts, rays_d, ray_idx)
+        raw = kilo_ops.kilo_forward(packed, net.num_models, aabb, res, pts, rays_d, ray_idx, kind=kind)
         e2 = E()
         out = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, r.ert, True)
         e3 = E()
@@ -397,14 +398,15 @@ def kilo_bench(args, dev, rank, world, dist):
             "metric": "rays/sec (KiloNeRF 800x800 frame, occupancy-grid marching + early termination)",
             "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if kind == "fp32" else DTYPE_LABEL["fp16x2"],
             "data": "synthetic (orbit camera, random-init cells, sigma head x10 + 0.5, sphere occupancy)",
             "config": {"workload": "BASELINE configs[3]: KiloNeRF 16^3 cells W=32 D=2, sphere |x|<0.75 occupancy at 256^3, "
                                    "step 0.005, ERT 0.01, 800x800 view per rank per step", "rays_per_frame": R,
                        "samples_per_frame": n, "samples_per_hit_ray": n / max(1.0, float((out[2] > 0).sum()))},
-            "roofline": {"kernel": "kilo_forward (route + counting sort + kilo_mlp_kernel)", "bound": "mfma",
-                         "achieved": flop / (ms["mlp"] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "roofline": {"kernel": "kilo_forward (route + counting sort + %s)" % ("kilo_mlp_kernel" if kind == "fp32" else
+                                   "kilo_mlp_h2_kernel: 3 fp16 MFMAs per fp32 product; peak = fp16 peak / 3"), "bound": "mfma",
+                         "achieved": flop / (ms["mlp"] * 1e-3) / 1e12, "peak": PEAK_TFLOPS[kind], "unit": "TFLOP/s",
+                         "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / PEAK_TFLOPS[kind], "traffic": None,
                          "samples_per_s": n / (ms["mlp"] * 1e-3)},
             "stage_ms": ms}
         if world == 1 and not args.no_cpu_baseline:

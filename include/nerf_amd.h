@@ -260,6 +260,15 @@ int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_cells);
 int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host, const float* pts,
                      const float* dirs, const int32_t* dir_index, int64_t n_points, float* raw, void* workspace,
                      int64_t workspace_bytes, nrf_stream_t stream);
+/* The same two calls with the cells' matrices on the fp16 matrix cores (network.py:123-167 again): every weight and
+ * layer input as two fp16 terms, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate, fp32 biases and heads
+ * (the "fp16x2" rule of nrf_mlp_forward_rays_fp16x2; fp32-class: tests/test_gpu_kilo.py holds the fp32 kernel's bars).
+ * packed_h2 has nrf_kilo_packed_floats(num_cells) floats like the fp32 records.  A point whose operands leave fp16's
+ * range (|a| >= 65520), and every point of a cell with such a weight, comes out as NaN. */
+int nrf_kilo_pack_weights_fp16x2(const float* const* tensors_host, int num_cells, float* packed_h2, nrf_stream_t stream);
+int nrf_kilo_forward_fp16x2(const float* packed_h2, int num_cells, const float* aabb_host, const int* res_host,
+                            const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points, float* raw,
+                            void* workspace, int64_t workspace_bytes, nrf_stream_t stream);
 
 /* nrf_kilo_pack_weights (and, with packed_t non-NULL, nrf_kilo_pack_weights_transposed) for the cells with
  * cell_mask[cell] != 0 only (int32 per cell, device); the other cells' records are left as they are. */

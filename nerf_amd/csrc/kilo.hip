@@ -20,6 +20,7 @@
 #include <cmath>
 
 #include "kilo_common.h"
+#include "split2h.h"
 
 namespace {
 
@@ -335,6 +336,215 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
     }
 }
 
+// ---- the tiny MLPs on the fp16 matrix cores (two fp16 terms per fp32 operand, split2h.h / mlp_fp16x2.hip) -------------
+// Same job structure and the same record size: the 24 KiB that hold a cell's matrices as fp32 A operands of 96
+// v_mfma_f32_32x32x2_f32 hold them as 12 k16-steps of (hi | lo) fp16 fragments, A operands of 36
+// v_mfma_f32_32x32x16_f16 (pts0: 4 steps, pts1: 2, feature: 2, view: 2 feature + 2 direction-encoding steps); the small
+// block (biases, head rows) is the fp32 kernel's, plus a status word: 1 if a weight of the cell lies outside fp16.
+constexpr int kKH2Steps = 12;
+constexpr int kKOffStatus = 264;
+static_assert(kKH2Steps * 2 * 1024 == kKiloSteps * 256 * 4 && kKOffStatus >= kKOffRgbB + 3 && kKOffStatus < kKiloSmall,
+              "the two formats share the record");
+
+__global__ __launch_bounds__(256) void kilo_pack_h2_kernel(KiloSrc s, int num_cells, float* __restrict__ packed) {
+    __shared__ float rec[kRecFloats];
+    __shared__ int bad;
+    const int cell = blockIdx.x;
+    if (threadIdx.x == 0) bad = 0;
+    stage_cell_record(s, cell, rec);
+    __syncthreads();
+    unsigned short* frag = reinterpret_cast<unsigned short*>(packed + int64_t(cell) * kKiloCellFloats);
+    for (int idx = threadIdx.x; idx < kKH2Steps * 512; idx += 256) {
+        const int jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
+        const int h = lane >> 5, row = lane & 31;
+        float v = 0.f;
+        if (step < 4) {            // pts0: 63 encoding columns, kernel slot order; k16-step = (k-block, half)
+            const int c = pe_col((step >> 1) * 16 + 8 * (step & 1) + jj, h, 10);
+            if (c >= 0) v = rec[REC_OFF(0) + row * 63 + c];
+        } else if (step < 6) {
+            v = rec[REC_OFF(2) + row * 32 + acc_row(8 * (step & 1) + jj, h)];
+        } else if (step < 8) {
+            v = rec[REC_OFF(4) + row * 32 + acc_row(8 * (step & 1) + jj, h)];
+        } else if (step < 10) {    // view layer, feature columns 0..31
+            v = rec[REC_OFF(8) + row * 59 + acc_row(8 * (step & 1) + jj, h)];
+        } else {                   // view layer, direction encoding columns 32..58
+            const int c = pe_col(8 * (step & 1) + jj, h, 4);
+            if (c >= 0) v = rec[REC_OFF(8) + row * 59 + 32 + c];
+        }
+        if (!(fabsf(v) < kF16Limit)) atomicOr(&bad, 1);
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(__fmul_rn(__fsub_rn(v, (float)hi), kLoScale));
+        frag[step * 1024 + lane * 8 + jj] = __builtin_bit_cast(unsigned short, hi);
+        frag[step * 1024 + 512 + lane * 8 + jj] = __builtin_bit_cast(unsigned short, lo);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kKiloSmall; i += 256) {   // the fp32 kernel's small block (kilo_pack_kernel)
+        float v = 0.f;
+        if (i < 128) {
+            const int layer = i >> 5, h = (i >> 4) & 1, r = i & 15;
+            const int off = layer == 0 ? REC_OFF(1) : layer == 1 ? REC_OFF(3) : layer == 2 ? REC_OFF(5) : REC_OFF(9);
+            v = rec[off + acc_row(r, h)];
+        } else if (i < 160) {
+            const int h = ((i - 128) >> 4) & 1, r = i & 15;
+            v = rec[REC_OFF(6) + acc_row(r, h)];
+        } else if (i < 256) {
+            const int j = i - 160, c = j >> 5, h = (j >> 4) & 1, r = j & 15;
+            v = rec[REC_OFF(10) + c * 32 + acc_row(r, h)];
+        } else if (i == kKOffSigB) {
+            v = rec[REC_OFF(7)];
+        } else if (i < kKOffRgbB + 3) {
+            v = rec[REC_OFF(11) + (i - kKOffRgbB)];
+        } else if (i == kKOffStatus) {
+            v = bad ? 1.f : 0.f;
+        }
+        packed[int64_t(cell) * kKiloCellFloats + kKiloSteps * 256 + i] = v;
+    }
+}
+
+// One 32x32 output block of a tiny layer on the fp16 pipe: per k16-step the two cross terms into a second accumulator at
+// scale 2^11 (started from the constant 0), hi.hi into the main one; the result is main + 2^-11 * second.
+template <int NKB>
+__device__ __forceinline__ f32x16 tiny_layer_h2(const u32x4 (*w)[2], f32x16 init, const u32x4 (*x)[2][2]) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 y = init, yl = zero16;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int st = kb * 2 + s2;
+            yl = st == 0 ? NRF_MFMA_F16(w[st][0], x[kb][s2][1], zero16) : NRF_MFMA_F16(w[st][0], x[kb][s2][1], yl);
+            yl = NRF_MFMA_F16(w[st][1], x[kb][s2][0], yl);
+            y = NRF_MFMA_F16(w[st][0], x[kb][s2][0], y);
+        }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 c = {kLoUnscale, kLoUnscale};
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {
+        const f32x2 l = {yl[t], yl[t + 1]}, b = {y[t], y[t + 1]};
+        const f32x2 r = __builtin_elementwise_fma(l, c, b);
+        y[t] = r[0], y[t + 1] = r[1];
+    }
+    return y;
+}
+
+// kilo_mlp_kernel with the cell's matrices as fp16x2 fragments (96 registers, as before).  Points whose operands leave
+// fp16's range, and every point of a cell with such a weight, come out as NaN (mlp_fp16x2.hip's guard).
+template <bool INDEXED>
+__global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
+                                                             const int* __restrict__ seg_start,
+                                                             const int* __restrict__ job_prefix,
+                                                             const int* __restrict__ perm, const float* __restrict__ pts,
+                                                             const float* __restrict__ dirs,
+                                                             const int* __restrict__ dir_index, float4* __restrict__ raw) {
+    __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    const int total_jobs = job_prefix[ncell];
+    for (int job = wave_global; job < total_jobs; job += n_waves) {
+        int lo = 0, hi = ncell;   // cell of this job: last c with job_prefix[c] <= job
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (job_prefix[mid] <= job) lo = mid; else hi = mid;
+        }
+        const int cell = lo;
+        const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
+        const int first = seg_b + (job - job_prefix[cell]) * 32 * job_tiles;
+        const float* cw = packed + int64_t(cell) * kKiloCellFloats;
+        u32x4 w[kKH2Steps][2];
+#pragma unroll
+        for (int s = 0; s < kKH2Steps; ++s) {
+            w[s][0] = reinterpret_cast<const u32x4*>(cw)[(2 * s) * 64 + lane];
+            w[s][1] = reinterpret_cast<const u32x4*>(cw)[(2 * s + 1) * 64 + lane];
+        }
+        float* sm_job = s_small[threadIdx.x >> 6];   // wave-private: no barrier (kilo_mlp_kernel)
+        {
+            const float4* src = reinterpret_cast<const float4*>(cw + kKiloSteps * 256);
+            reinterpret_cast<float4*>(sm_job)[lane] = src[lane];
+            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = src[64 + lane];
+        }
+        const float* bias_job = sm_job + kKOffBias + h * 16;
+        const float sb = cw[kKiloSteps * 256 + kKOffSigB], rb0 = cw[kKiloSteps * 256 + kKOffRgbB],
+                    rb1 = cw[kKiloSteps * 256 + kKOffRgbB + 1], rb2 = cw[kKiloSteps * 256 + kKOffRgbB + 2];
+        const float poison = cw[kKiloSteps * 256 + kKOffStatus] != 0.f ? __builtin_inff() : 0.f;
+        auto lds16 = [](const float* p) { return *reinterpret_cast<const f32x16*>(p); };
+
+        const int last = seg_e - 1;   // gather pipeline: kilo_mlp_kernel
+        auto tile_id = [&](int t0) { const int k = t0 + j; return unsigned(perm[unsigned(k < last ? k : last)]); };
+        auto dir_of = [&](unsigned id) { return INDEXED ? unsigned(dir_index[id]) : id; };
+        unsigned id_c = tile_id(first), id_n = tile_id(first + 32), id_nn = tile_id(first + 64);
+        float pc[3], pn[3], dc[3];
+        unsigned di_n;
+        {
+            const unsigned di_c = dir_of(id_c);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pc[a] = pts[id_c * 3u + a], dc[a] = dirs[di_c * 3u + a];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pn[a] = pts[id_n * 3u + a];
+            di_n = dir_of(id_n);
+        }
+        for (int t0 = first; t0 < seg_e && t0 < first + 32 * job_tiles; t0 += 32) {
+            const bool valid = t0 + j < seg_e;
+            const unsigned id = id_c;
+            const float px = pc[0], py = pc[1], pz = pc[2], dx = dc[0], dy = dc[1], dz = dc[2];
+            {
+                float dn[3], pnn[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) dn[a] = dirs[di_n * 3u + a], pnn[a] = pts[id_nn * 3u + a];
+                const unsigned di_nn = dir_of(id_nn);
+                const unsigned id_nnn = tile_id(t0 + 96);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pc[a] = pn[a], dc[a] = dn[a], pn[a] = pnn[a];
+                id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_n = di_nn;
+            }
+            float ovf = poison;
+            f32x16 e[2];
+            u32x4 xpe[2][2][2], xh[1][2][2], xv[2][2][2];
+            encode_pe_doubling<10>(px, py, pz, h, e);
+            split_block_f16(e[0], xpe[0], ovf);
+            split_block_f16(e[1], xpe[1], ovf);
+            int again = 0;   // keeps the LDS reads below inside the tile loop (kilo_mlp_kernel)
+            asm volatile("" : "+v"(again));
+            const float* bias_h = bias_job + again;
+            const float* sm = sm_job + again;
+            f32x16 y = relu16(tiny_layer_h2<2>(w, lds16(bias_h), xpe));             // pts_linears 0 (network.py:132-138)
+            split_block_f16(y, xh[0], ovf);
+            y = relu16(tiny_layer_h2<1>(w + 4, lds16(bias_h + 32), xh));            // pts_linears 1
+            float sigma = 0.f;                                                      // sigma_linear (:142-144)
+            {
+                const f32x16 sw = lds16(sm + kKOffSigW + h * 16);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sigma = fmaf(sw[t], y[t], sigma);
+            }
+            split_block_f16(y, xh[0], ovf);
+            y = tiny_layer_h2<1>(w + 6, lds16(bias_h + 64), xh);                    // feature_linear (:147-149), no activation
+            split_block_f16(y, xv[0], ovf);
+            encode_pe_doubling<4>(dx, dy, dz, h, e);
+            split_block_f16(e[0], xv[1], ovf);
+            const f32x16 hv = relu16(tiny_layer_h2<2>(w + 8, lds16(bias_h + 96), xv));   // view_linears on cat([feature, dirs]) (:152-156)
+            float r = 0.f, g = 0.f, b = 0.f;                                        // rgb_linear (:159-161)
+            {
+                const f32x16 r0 = lds16(sm + kKOffRgbW + h * 16), r1 = lds16(sm + kKOffRgbW + 32 + h * 16),
+                             r2 = lds16(sm + kKOffRgbW + 64 + h * 16);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    r = fmaf(r0[t], hv[t], r);
+                    g = fmaf(r1[t], hv[t], g);
+                    b = fmaf(r2[t], hv[t], b);
+                }
+            }
+            r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
+            ovf = fmaxf(ovf, __shfl_xor(ovf, 32));
+            if (h == 0 && valid) {
+                float4 o = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
+                if (!(ovf < kF16Limit)) o = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                raw[id] = o;
+            }
+        }
+    }
+}
+
 // ---- generic exclusive scan of int32 (three small kernels) ---------------------------------
 constexpr int kScanBlock = 1024;
 __global__ void scan_block_kernel(const int* __restrict__ in, int64_t n, int* __restrict__ out, int* __restrict__ sums) {
@@ -617,7 +827,7 @@ NRF_EXPORT int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_ce
 // `src` (optional): the 12 parameter tensors; the cells the batch routes to (and `done`, if given, does not mark as
 // packed already) are packed from them into `packed` (and `packed_t`, if given) between the routing histogram and the
 // MLP launch.
-static int kilo_forward_impl(const KiloSrc* src, const int32_t* done, float* packed_t, const float* packed, int num_cells, const float* aabb_host,
+static int kilo_forward_impl(bool h2, const KiloSrc* src, const int32_t* done, float* packed_t, const float* packed, int num_cells, const float* aabb_host,
                              const int* res_host, const float* pts, const float* dirs, const int32_t* dir_index,
                              int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream_) {
     if (n_points < 0 || num_cells <= 0 || n_points > (1LL << 28)) return NRF_ERR_SHAPE;  // 32-bit byte offsets in the kernels
@@ -650,7 +860,14 @@ static int kilo_forward_impl(const KiloSrc* src, const int32_t* done, float* pac
     }
     kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, job_tiles, seg_start, cursor, job_prefix);
     kilo_scatter_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(cell, n_points, num_cells, cursor, perm);
-    if (dir_index)
+    if (h2) {   // records from nrf_kilo_pack_weights_fp16x2
+        if (dir_index)
+            kilo_mlp_h2_kernel<true><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm,
+                                                                              pts, dirs, dir_index, reinterpret_cast<float4*>(raw));
+        else
+            kilo_mlp_h2_kernel<false><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm,
+                                                                               pts, dirs, dir_index, reinterpret_cast<float4*>(raw));
+    } else if (dir_index)
         kilo_mlp_kernel<true><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
                                                                        dirs, dir_index, reinterpret_cast<float4*>(raw));
     else
@@ -662,8 +879,31 @@ static int kilo_forward_impl(const KiloSrc* src, const int32_t* done, float* pac
 NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host,
                                 const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
                                 float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream) {
-    return kilo_forward_impl(nullptr, nullptr, nullptr, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
+    return kilo_forward_impl(false, nullptr, nullptr, nullptr, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
                              workspace, workspace_bytes, stream);
+}
+
+// The same with the cells' matrices on the fp16 matrix cores (two fp16 terms per operand, three MFMAs per product):
+// packed_h2 from nrf_kilo_pack_weights_fp16x2 (nrf_kilo_packed_floats(num_cells) floats, like the fp32 records).
+NRF_EXPORT int nrf_kilo_forward_fp16x2(const float* packed_h2, int num_cells, const float* aabb_host, const int* res_host,
+                                       const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
+                                       float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream) {
+    return kilo_forward_impl(true, nullptr, nullptr, nullptr, packed_h2, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points,
+                             raw, workspace, workspace_bytes, stream);
+}
+
+NRF_EXPORT int nrf_kilo_pack_weights_fp16x2(const float* const* tensors, int num_cells, float* packed_h2, nrf_stream_t stream) {
+    if (!tensors || !packed_h2) return NRF_ERR_NULL;
+    if (num_cells <= 0) return NRF_ERR_SHAPE;
+    KiloSrc s;
+    for (int i = 0; i < 12; ++i) {
+        if (!tensors[i]) return NRF_ERR_NULL;
+        s.t[i] = tensors[i];
+    }
+    if (!nrf_aligned16(packed_h2)) return NRF_ERR_ALIGN;
+    nrf_launch_begin();
+    kilo_pack_h2_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, packed_h2);
+    return nrf_launch_status();
 }
 
 NRF_EXPORT int nrf_kilo_forward_packing(const float* const* tensors, const int32_t* packed_cells, float* packed, float* packed_t,
@@ -677,7 +917,7 @@ NRF_EXPORT int nrf_kilo_forward_packing(const float* const* tensors, const int32
         if (!tensors[i]) return NRF_ERR_NULL;
         s.t[i] = tensors[i];
     }
-    return kilo_forward_impl(&s, packed_cells, packed_t, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
+    return kilo_forward_impl(false, &s, packed_cells, packed_t, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
                              workspace, workspace_bytes, stream);
 }
 

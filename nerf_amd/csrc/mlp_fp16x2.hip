@@ -41,23 +41,12 @@ constexpr int kHLead = H2_LEAD;                       // output blocks a hidden-
 constexpr int kHLook = H2_LOOK;                       // LDS -> register look-ahead of the weight fragments, in steps (< 4)
 constexpr int64_t kHSmallFloatOff = int64_t(kXStreamSteps) * kHStepBytes / 4;   // fp32 small block behind the stream
 constexpr int64_t kHStatusOff = kHSmallFloatOff * 4 + int64_t(kSmallFloats) * 4;   // bytes: one status word behind the small block
-constexpr float kF16Limit = 65520.f;                  // |a| >= this rounds to fp16 infinity
 constexpr int kHLdsConstOff = kHRing * kHChunkBytes;                             // 96 KiB
 constexpr int kHLdsBytes = kHLdsConstOff + kSmallFloats * 4;                     // + 12.1 KiB
 static_assert(kHLdsBytes <= 160 * 1024, "LDS budget");
 static_assert(kHPieces * (kHRing - 2) + kHLook < 64, "vmcnt is a 6-bit counter");
 
-// a 32-row block held as 16 accumulator registers -> the B fragments [k16-step][term] of its two terms
-__device__ __forceinline__ void split_tile_h(const f32x16& v, u32x4 (&out)[2][2]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned hi, lo;
-            split_pair_f16(v[8 * s + 2 * i], v[8 * s + 2 * i + 1], hi, lo);
-            out[s][0][i] = hi, out[s][1][i] = lo;
-        }
-}
+__device__ __forceinline__ void split_tile_h(const f32x16& v, u32x4 (&out)[2][2]) { split_block_f16(v, out); }
 
 // ---- weight packing ------------------------------------------------------------------------
 __global__ void hpack_layer_kernel(XPackLayer p, unsigned* status) {   // one thread writes the two terms of one weight
@@ -154,11 +143,6 @@ __device__ __forceinline__ void hr_start(HRing& st, const char* stream_base, cha
     }
 }
 
-// ovf = max(ovf, |a|, |b|) in one instruction.  The operands are VALU results (see split2h.h on inline asm and MFMAs).
-__device__ __forceinline__ void track_max(float& ovf, float a, float b) {
-    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovf) : "v"(a), "v"(b));
-}
-
 // Input op of a hidden-type layer: X[kb] (two-term B fragments) from Y[kb] of the previous layer, one register pair
 // at a time in three sub-slices (activation + hi, the two residuals, lo: 3 + 2 + 2 VALU instructions).
 struct OpInH : OpInBase {
@@ -175,9 +159,16 @@ struct OpInH : OpInBase {
             p0 = pk_f16(sa, sb);
             x[q / 4][0][q % 4] = p0;
         } else if (phase == 1) {
+#ifndef H2_ABL_NOLO
             ra = f16_residual_lo(sa, p0), rb = f16_residual_hi(sb, p0);
+#endif
+#ifndef H2_ABL_NOTRACK
             track_max(ovf, sa, sb);
+#endif
         } else {
+#ifdef H2_ABL_NOLO
+            return;
+#endif
             x[q / 4][1][q % 4] = pk_f16_scaled(ra, rb);
         }
     }
@@ -198,9 +189,22 @@ __device__ __forceinline__ void fold_slice(f32x16& y, const f32x16& base, const 
     return;
 #endif
     f32x16 v = y;   // whole-vector read / write: element stores into the block array keep it out of registers
+#ifdef H2_FOLD_SCALAR
 #pragma unroll
     for (int t = 0; t < 16; ++t)
         if (t >= t0 && t < t1) v[t] = fmaf(yl[t], kLoUnscale, base[t]);
+#else
+    // two elements per instruction (v_pk_fma_f32); every slice is a whole number of even-aligned pairs
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 c = {kLoUnscale, kLoUnscale};
+#pragma unroll
+    for (int t = 0; t < 16; t += 2)
+        if (t >= t0 && t < t1) {
+            const f32x2 l = {yl[t], yl[t + 1]}, b = {base[t], base[t + 1]};
+            const f32x2 r = __builtin_elementwise_fma(l, c, b);
+            v[t] = r[0], v[t + 1] = r[1];
+        }
+#endif
     y = v;
 }
 

@@ -47,6 +47,28 @@ __device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& hi, u
     hi = pk_f16(a, b);
     lo = pk_f16_scaled(f16_residual_lo(a, hi), f16_residual_hi(b, hi));
 }
+// ovf = max(ovf, |a|, |b|) in one instruction: the range guard's running maximum of what was fed to a split
+__device__ __forceinline__ void track_max(float& ovf, float a, float b) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(ovf) : "v"(a), "v"(b));
+}
+constexpr float kF16Limit = 65520.f;   // |a| >= this rounds to fp16 infinity
+
+// a 32-row block held as 16 accumulator-order registers -> the B fragments [k16-step][term] of its two terms
+__device__ __forceinline__ void split_block_f16(const f32x16& v, u32x4 (&out)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned hi, lo;
+            split_pair_f16(v[8 * s + 2 * i], v[8 * s + 2 * i + 1], hi, lo);
+            out[s][0][i] = hi, out[s][1][i] = lo;
+        }
+}
+__device__ __forceinline__ void split_block_f16(const f32x16& v, u32x4 (&out)[2][2], float& ovf) {
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) track_max(ovf, v[t], v[t + 1]);
+    split_block_f16(v, out);
+}
 }  // namespace
 
 #define NRF_MFMA_F16(a, b, c) \

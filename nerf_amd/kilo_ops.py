@@ -30,9 +30,12 @@ def _grid_args(aabb, res):
     return aabb, res, aabb.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p)
 
 
-def kilo_pack_weights(tensors, out: torch.Tensor | None = None) -> torch.Tensor:
-    """12 batched (cells, ...) tensors in KILO_TENSORS order -> per-cell MFMA streaming layout."""
+def kilo_pack_weights(tensors, out: torch.Tensor | None = None, kind: str = "fp32") -> torch.Tensor:
+    """12 batched (cells, ...) tensors in KILO_TENSORS order -> per-cell MFMA streaming layout.  ``kind`` "fp16x2": the
+    records of nrf_kilo_forward_fp16x2 (same size; every matrix weight as two fp16 terms)."""
     assert len(tensors) == 12
+    if kind not in ("fp32", "fp16x2"):
+        raise ValueError(f"kind {kind!r}: expected 'fp32' or 'fp16x2'")
     ts = [_f32(t.detach(), "kilo tensor") for t in tensors]
     num_cells = ts[0].shape[0]
     for t, (name, shape, _) in zip(ts, KILO_TENSORS):
@@ -45,13 +48,14 @@ def kilo_pack_weights(tensors, out: torch.Tensor | None = None) -> torch.Tensor:
         out = torch.empty(n, dtype=torch.float32, device=dev)
     ptrs = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
     with torch.cuda.device(dev):
-        check(lib().nrf_kilo_pack_weights(ptrs, num_cells, _ptr(out), _stream(out)), "nrf_kilo_pack_weights")
+        fn = lib().nrf_kilo_pack_weights if kind == "fp32" else lib().nrf_kilo_pack_weights_fp16x2
+        check(fn(ptrs, num_cells, _ptr(out), _stream(out)), "nrf_kilo_pack_weights" + ("" if kind == "fp32" else "_fp16x2"))
     return out
 
 
-def kilo_pack_state_dict(sd: dict, device, prefix: str = "model.") -> torch.Tensor:
+def kilo_pack_state_dict(sd: dict, device, prefix: str = "model.", kind: str = "fp32") -> torch.Tensor:
     return kilo_pack_weights([torch.as_tensor(sd[prefix + n]).to(device=device, dtype=torch.float32)
-                              for n, _, _ in KILO_TENSORS])
+                              for n, _, _ in KILO_TENSORS], kind=kind)
 
 
 def kilo_route(pts: torch.Tensor, aabb, res) -> torch.Tensor:
@@ -108,8 +112,10 @@ def kilo_packed_bwd_floats(num_cells: int) -> int:
 
 
 def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, workspace=None,
-                 return_workspace: bool = False, pack_from=None, packed_t=None, packed_cells=None):
+                 return_workspace: bool = False, pack_from=None, packed_t=None, packed_cells=None, kind: str = "fp32"):
     """raw (n, 4) = [r, g, b, sigma] per point; dirs (n, 3) or (m, 3) with int32 dir_index (n,).
+    ``kind`` "fp16x2": ``packed`` from kilo_pack_weights(kind="fp16x2"), the tiny MLPs on the fp16 matrix cores
+    (fp32-class; operands beyond fp16's range give NaN).
     ``return_workspace``: also return the workspace (the points' order by cell), which kilo_backward needs.
     ``pack_from``: the 12 parameter tensors (or a ParamPointers); the cells this batch routes to are packed from them
     into ``packed`` (and ``packed_t``) on the way (nrf_kilo_forward_packing), except those ``packed_cells`` (int32 per
@@ -129,6 +135,8 @@ def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, w
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=pts.device)
     with torch.cuda.device(pts.device):
+        if kind not in ("fp32", "fp16x2") or (kind != "fp32" and pack_from is not None):
+            raise NrfError(f"kilo_forward: kind {kind!r} (packing on the way is fp32 only)")
         if pack_from is not None:
             pp = _param_pointers(pack_from)
             if pp.num_cells != num_cells:
@@ -144,8 +152,9 @@ def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, w
                                                  _ptr(dir_index), n, _ptr(raw), _ptr(workspace), workspace.numel(),
                                                  _stream(pts)), "nrf_kilo_forward_packing")
         else:
-            check(lib().nrf_kilo_forward(_ptr(packed), num_cells, pa, pr, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,
-                                         _ptr(raw), _ptr(workspace), workspace.numel(), _stream(pts)), "nrf_kilo_forward")
+            fn = lib().nrf_kilo_forward if kind == "fp32" else lib().nrf_kilo_forward_fp16x2
+            check(fn(_ptr(packed), num_cells, pa, pr, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,
+                     _ptr(raw), _ptr(workspace), workspace.numel(), _stream(pts)), "nrf_kilo_forward")
     return (raw, workspace) if return_workspace else raw
 
 

@@ -83,6 +83,9 @@ class KiloNetwork(nn.Module):
         self.model = BatchedKiloNeRF(self.num_models)
         self._packed = None
         self._packed_key = None
+        # "fp32" (the reference's arithmetic on the fp32 MFMA) or "fp16x2" (fp32-class on the fp16 MFMA: every operand
+        # as two fp16 terms; inference -- the training kernels read the fp32 records)
+        self.mlp_dtype = "fp32"
 
     def grid(self):
         """(aabb, res) from the registered buffers the reference routes with (network.py:189-191, :322), which
@@ -92,10 +95,10 @@ class KiloNetwork(nn.Module):
     def packed(self) -> torch.Tensor:
         """Per-cell streaming layout, repacked only when a parameter changed (tensor versions)."""
         ts = self.model.tensors()
-        key = tuple((t.data_ptr(), t._version) for t in ts)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (self.mlp_dtype,)
         if self._packed is None or key != self._packed_key or self._packed.device != ts[0].device:
             self._packed = kilo_ops.kilo_pack_weights(ts, self._packed if self._packed is not None and
-                                                      self._packed.device == ts[0].device else None)
+                                                      self._packed.device == ts[0].device else None, kind=self.mlp_dtype)
             self._packed_key = key
         return self._packed
 
@@ -110,7 +113,7 @@ class KiloNetwork(nn.Module):
             di = torch.arange(R, device=pts.device, dtype=torch.int32).repeat_interleave(S)
         aabb, res = self.grid()
         raw = kilo_ops.kilo_forward(self.packed(), self.num_models, aabb, res, pts.reshape(-1, 3),
-                                    viewdirs, di).view(R, S, 4)
+                                    viewdirs, di, kind=self.mlp_dtype).view(R, S, 4)
         return raw[..., :3], raw[..., 3:4]
 
     def get_color_reg_loss(self):
@@ -143,6 +146,19 @@ class KiloNetView:
         self._packed = None
         self._packed_key = None
         self._grid, self._grid_key = None, None
+        self._mlp_dtype = "fp32"
+
+    @property
+    def mlp_dtype(self) -> str:
+        return getattr(self.net, "mlp_dtype", self._mlp_dtype)
+
+    @mlp_dtype.setter
+    def mlp_dtype(self, kind: str):
+        if kind not in ("fp32", "fp16x2"):
+            raise kilo_ops.NrfError(f"mlp_dtype {kind!r}: expected 'fp32' or 'fp16x2'")
+        if hasattr(self.net, "mlp_dtype"):
+            self.net.mlp_dtype = kind
+        self._mlp_dtype = kind
 
     def tensors(self):
         model = getattr(self.net, "model", None)
@@ -167,10 +183,10 @@ class KiloNetView:
         if hasattr(self.net, "packed"):
             return self.net.packed()
         ts = self.tensors()
-        key = tuple((t.data_ptr(), t._version) for t in ts)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (self.mlp_dtype,)
         if self._packed is None or key != self._packed_key or self._packed.device != ts[0].device:
             same_dev = self._packed is not None and self._packed.device == ts[0].device
-            self._packed = kilo_ops.kilo_pack_weights(ts, self._packed if same_dev else None)
+            self._packed = kilo_ops.kilo_pack_weights(ts, self._packed if same_dev else None, kind=self.mlp_dtype)
             self._packed_key = key
         return self._packed
 
@@ -198,6 +214,8 @@ class _KiloRenderFn(torch.autograd.Function):
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, renderer.occ_grid, aabb, renderer.near,
                                                                     renderer.far, renderer.step)
         renderer.last_num_samples = int(pts.shape[0])
+        if net.mlp_dtype != "fp32":
+            raise kilo_ops.NrfError("KiloRenderer: the backward kernels read the fp32 records; train with mlp_dtype='fp32'")
         packed = net.packed()
         raw, ws = kilo_ops.kilo_forward(packed, net.num_models, aabb, res, pts, d, ray_idx, return_workspace=True)
         rgb, depth, acc = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, renderer.ert, renderer.white_bkgd)
@@ -227,10 +245,14 @@ class KiloRenderer(nn.Module):
     """``Renderer(net)`` for KiloNeRF.  ``occ_grid``: (rx,ry,rz) bool/uint8 tensor (the reference loads or bakes
     it in ``__init__``, volumn_renderer.py:36-44; here it is handed in or set later with ``set_occ_grid``)."""
 
-    def __init__(self, net: KiloNetwork, cfg=None, occ_grid: torch.Tensor | None = None):
+    def __init__(self, net: KiloNetwork, cfg=None, occ_grid: torch.Tensor | None = None, mlp_dtype: str | None = None):
+        """``mlp_dtype``: "fp32" (default) or "fp16x2" -- inference with the tiny MLPs on the fp16 matrix cores
+        (nrf_kilo_forward_fp16x2: fp32-class, operands must lie in fp16's range); training always reads fp32 records."""
         super().__init__()
         self.net = net
         self.view = KiloNetView(net)
+        if mlp_dtype is not None:
+            self.view.mlp_dtype = mlp_dtype
         ref_cfg = None
         if cfg is None:
             try:  # inside the reference tree: its global config (volumn_renderer.py:5)
@@ -335,7 +357,8 @@ class KiloRenderer(nn.Module):
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, occ, aabb, self.near, self.far, self.step)
         self.last_num_samples = int(pts.shape[0])
         if pts.shape[0]:
-            raw = kilo_ops.kilo_forward(self.view.packed(), self.view.num_models, aabb, res, pts, d, ray_idx)
+            raw = kilo_ops.kilo_forward(self.view.packed(), self.view.num_models, aabb, res, pts, d, ray_idx,
+                                        kind=self.view.mlp_dtype)
         else:
             raw = torch.empty((0, 4), dtype=torch.float32, device=o.device)
         return kilo_ops.kilo_composite(raw, ts, te, offsets, counts, self.ert, self.white_bkgd)

@@ -29,10 +29,12 @@ def _sd(seed=7, gain=20.0, bias=1.0):
     return make_kilo_state_dict_arrays(seed, 4096, gain, bias)
 
 
-@pytest.fixture(scope="module")
-def packed(dev):
+@pytest.fixture(scope="module", params=["fp32", "fp16x2"])
+def packed(dev, request):
+    """(records, kind): the fp32 MFMA records, and the two-fp16-term records of nrf_kilo_forward_fp16x2 -- one set of
+    tests and one set of bars for both kernels."""
     from nerf_amd import kilo_ops
-    return kilo_ops.kilo_pack_state_dict(_sd(), dev)
+    return kilo_ops.kilo_pack_state_dict(_sd(), dev, kind=request.param), request.param
 
 
 def test_route_bit_exact(golden, dev):
@@ -71,7 +73,8 @@ def test_tiny_mlp_matches_reference(golden, dev, packed):
     from nerf_amd import kilo_ops
     from oracle import kilo_oracle as K
     fx = golden("kilo_network")
-    raw = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(fx["pts"], dev), _t(fx["dirs"], dev)).cpu().numpy()
+    packed, kind = packed
+    raw = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(fx["pts"], dev), _t(fx["dirs"], dev), kind=kind).cpu().numpy()
     ref = np.concatenate([fx["rgb"].reshape(-1, 3), fx["sigma"].reshape(-1, 1)], -1)
     f64 = K.network_forward(_sd(), torch.from_numpy(fx["pts"]), torch.from_numpy(fx["dirs"]), AABB[:3], AABB[3:], RES,
                             dtype=torch.float64).numpy()
@@ -80,7 +83,8 @@ def test_tiny_mlp_matches_reference(golden, dev, packed):
     # (R, S, 3) points with one direction per ray == dir_index form of the entry point
     R, S = fx["rgb_rays"].shape[:2]
     di = torch.arange(R, device=dev, dtype=torch.int32).repeat_interleave(S)
-    raw3 = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(fx["pts"][:R * S], dev), _t(fx["dirs"][:R], dev), di).cpu().numpy()
+    raw3 = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(fx["pts"][:R * S], dev), _t(fx["dirs"][:R], dev), di,
+                                 kind=kind).cpu().numpy()
     ref3 = np.concatenate([fx["rgb_rays"].reshape(-1, 3), fx["sigma_rays"].reshape(-1, 1)], -1)
     assert np.abs(raw3[:, :3] - ref3[:, :3]).max() < 5e-5
     assert np.abs(raw3[:, 3] - ref3[:, 3]).max() < 5e-4
@@ -95,7 +99,8 @@ def test_tiny_mlp_matches_oracle_sizes(dev, packed, n, spread):
     pts = (rng.uniform(-1, 1, size=(n, 3)) * spread + (0.31 if spread < 1 else 0.0)).astype(np.float32)
     dirs = rng.normal(size=(n, 3)).astype(np.float32)
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
-    raw = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev)).cpu().numpy()
+    packed, kind = packed
+    raw = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev), kind=kind).cpu().numpy()
     sub = slice(0, min(n, 20000))
     ref = K.network_forward(_sd(), torch.from_numpy(pts[sub]), torch.from_numpy(dirs[sub]), AABB[:3], AABB[3:], RES).numpy()
     f64 = K.network_forward(_sd(), torch.from_numpy(pts[sub]), torch.from_numpy(dirs[sub]), AABB[:3], AABB[3:], RES,
@@ -105,8 +110,35 @@ def test_tiny_mlp_matches_oracle_sizes(dev, packed, n, spread):
     _check(raw[sub, 3], ref[:, 3], f64[:, 3], 2e-4)
     # order independence: a permuted batch gives the permuted result, bit for bit
     perm = rng.permutation(n)
-    raw_p = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts[perm], dev), _t(dirs[perm], dev)).cpu().numpy()
+    raw_p = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts[perm], dev), _t(dirs[perm], dev), kind=kind).cpu().numpy()
     assert np.array_equal(raw_p, raw[perm])
+
+
+def test_tiny_mlp_fp16x2_range_guard(dev):
+    """Beyond fp16's range the fp16x2 kernel answers NaN, for the point (a huge coordinate) or for the cell (a huge
+    weight), and leaves every other point's bits alone."""
+    from nerf_amd import kilo_ops
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-1, 1, size=(4096, 3)).astype(np.float32)
+    dirs = rng.normal(size=(4096, 3)).astype(np.float32)
+    sd = _sd()
+    clean = kilo_ops.kilo_forward(kilo_ops.kilo_pack_state_dict(sd, dev, kind="fp16x2"), 4096, AABB, RES, _t(pts, dev),
+                                  _t(dirs, dev), kind="fp16x2")
+    assert torch.isfinite(clean).all()
+    far = pts.copy()
+    far[100, 1] = 1.0e5          # routed to a border cell (the reference clamps the index) and refused there
+    out = kilo_ops.kilo_forward(kilo_ops.kilo_pack_state_dict(sd, dev, kind="fp16x2"), 4096, AABB, RES, _t(far, dev),
+                                _t(dirs, dev), kind="fp16x2")
+    ok = torch.ones(4096, dtype=torch.bool, device=dev)
+    ok[100] = False
+    assert torch.isnan(out[100]).all() and torch.equal(out[ok], clean[ok])
+    cell = int(kilo_ops.kilo_route(_t(pts, dev), AABB, RES)[7])
+    big = {k: v.copy() for k, v in sd.items()}
+    big["model.pts_linears_weights.1"][cell, 3, 5] = 7.0e4
+    out = kilo_ops.kilo_forward(kilo_ops.kilo_pack_state_dict(big, dev, kind="fp16x2"), 4096, AABB, RES, _t(pts, dev),
+                                _t(dirs, dev), kind="fp16x2")
+    in_cell = kilo_ops.kilo_route(_t(pts, dev), AABB, RES) == cell
+    assert bool(in_cell[7]) and torch.isnan(out[in_cell]).all() and torch.equal(out[~in_cell], clean[~in_cell])
 
 
 def _sphere_occ(n, radius=0.75):
@@ -194,7 +226,8 @@ def test_composite_packed_vs_oracle(dev, ert, white):
     assert np.abs(depth.cpu().numpy() - r_depth).max() < 1e-4 * 6
 
 
-def test_kilo_renderer_vs_oracle(dev):
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "fp16x2"])
+def test_kilo_renderer_vs_oracle(dev, mlp_dtype):
     """KiloRenderer(net)(batch) end to end (march -> route/sort -> tiny MLPs -> packed composite) against the
     oracle's render on a 24x24 view of the sphere grid; un-normalised camera directions as the reference passes."""
     from nerf_amd.camera import LEGO_CAMERA_ANGLE_X, pose_spherical
@@ -208,7 +241,7 @@ def test_kilo_renderer_vs_oracle(dev):
     net = net.to(dev)
     occ = _sphere_occ(256)
     cfg = default_kilo_cfg()
-    r = KiloRenderer(net, cfg, _t(occ, dev))
+    r = KiloRenderer(net, cfg, _t(occ, dev), mlp_dtype=mlp_dtype)
     o, d = O.raygen(pose_spherical(20.0, -30.0, 4.031), 24, 24, LEGO_CAMERA_ANGLE_X * 0.9)   # ~160 of 576 rays hit the sphere
     o, d = o.reshape(-1, 3).astype(np.float32), d.reshape(-1, 3).astype(np.float32)
     out = r({"xyz": _t(o, dev)[None], "viewdirs": _t(d, dev)[None]}, is_training=False)
