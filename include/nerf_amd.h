@@ -316,6 +316,11 @@ int64_t nrf_occ_bake_workspace_bytes(int64_t n_cells);
 int nrf_occ_bake(const float* packed_teacher, const float* aabb_host, const int* res_host, float threshold,
                  int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
                  nrf_stream_t stream);
+/* nrf_occ_bake with the teacher on the fp16x2 kernel (packed_teacher_h2 from nrf_pack_weights_fp16x2): 3.7x the bake
+ * rate; densities are fp32-class, so only cells whose maximum density sits within rounding of the threshold can differ. */
+int nrf_occ_bake_fp16x2(const void* packed_teacher_h2, const float* aabb_host, const int* res_host, float threshold,
+                        int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
+                        nrf_stream_t stream);
 
 /* The NeRF renderer's own occupancy grid: Renderer._build_occ_grid (src/models/nerf/renderer/volume_renderer.py:156-197).
  * ONE point per voxel at torch.linspace(min, max, res)[i] per axis (:170-178), through `packed` (the network's

@@ -32,7 +32,7 @@ SYMBOLS = (
     "nrf_packed_bf16x3_bytes", "nrf_pack_weights_bf16x3", "nrf_mlp_forward_rays_bf16x3", "nrf_mlp_forward_points_bf16x3",
     "nrf_render_bf16x3",
     "nrf_packed_fp16x2_bytes", "nrf_pack_weights_fp16x2", "nrf_packed_fp16x2_status", "nrf_mlp_forward_rays_fp16x2", "nrf_mlp_forward_points_fp16x2",
-    "nrf_render_fp16x2", "nrf_mlp_forward_rays_train_fp16x2", "nrf_kilo_pack_weights_fp16x2", "nrf_kilo_forward_fp16x2",
+    "nrf_render_fp16x2", "nrf_mlp_forward_rays_train_fp16x2", "nrf_kilo_pack_weights_fp16x2", "nrf_kilo_forward_fp16x2", "nrf_occ_bake_fp16x2",
 )
 
 P = C.c_void_p
@@ -168,6 +168,8 @@ def lib() -> C.CDLL:
     L.nrf_occ_bake_workspace_bytes.argtypes = [I64]
     L.nrf_occ_bake.restype = INT
     L.nrf_occ_bake.argtypes = [P, P, P, F, I64, I64, P, P, I64, P]
+    L.nrf_occ_bake_fp16x2.restype = INT
+    L.nrf_occ_bake_fp16x2.argtypes = [P, P, P, F, I64, I64, P, P, I64, P]
     L.nrf_occ_bake_vertices_workspace_bytes.restype = I64
     L.nrf_occ_bake_vertices_workspace_bytes.argtypes = [I64]
     L.nrf_occ_bake_vertices.restype = INT

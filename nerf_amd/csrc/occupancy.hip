@@ -69,7 +69,8 @@ static int64_t bake_workspace_bytes(int64_t n_cells, int sub) {
 }
 
 static int bake(const float* packed, const float* aabb_host, const int* res_host, float threshold, int64_t first_cell,
-                int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes, bool vertices, nrf_stream_t stream_) {
+                int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes, bool vertices, nrf_stream_t stream_,
+                bool h2 = false) {
     if (n_cells < 0 || first_cell < 0) return NRF_ERR_SHAPE;
     if (n_cells == 0) return NRF_OK;
     if (!packed || !aabb_host || !res_host || !occ || !workspace) return NRF_ERR_NULL;
@@ -94,7 +95,9 @@ static int bake(const float* packed, const float* aabb_host, const int* res_host
     if (vertices) occ_vertex_points_kernel<<<pgrid, 256, 0, stream>>>(g, first_cell, n_cells, pts);
     else occ_points_kernel<<<pgrid, 256, 0, stream>>>(g, first_cell, n_cells, pts);
     if (int st = nrf_launch_status()) return st;
-    if (int st = nrf_mlp_forward_points(packed, pts, dirs, np, raw, stream_)) return st;
+    if (int st = h2 ? nrf_mlp_forward_points_fp16x2(packed, pts, dirs, np, raw, stream_)
+                    : nrf_mlp_forward_points(packed, pts, dirs, np, raw, stream_))
+        return st;
     nrf_launch_begin();
     if (vertices)
         occ_reduce_kernel<1><<<cgrid, 256, 0, stream>>>(reinterpret_cast<const float4*>(raw), n_cells, threshold, occ + first_cell);
@@ -110,6 +113,14 @@ NRF_EXPORT int nrf_occ_bake(const float* packed_teacher, const float* aabb_host,
                             nrf_stream_t stream) {
     return bake(packed_teacher, aabb_host, res_host, threshold, first_cell, n_cells, occ, workspace, workspace_bytes, false,
                 stream);
+}
+
+// nrf_occ_bake with the teacher evaluated by nrf_mlp_forward_points_fp16x2 (packed_teacher_h2: nrf_pack_weights_fp16x2)
+NRF_EXPORT int nrf_occ_bake_fp16x2(const void* packed_teacher_h2, const float* aabb_host, const int* res_host, float threshold,
+                                   int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
+                                   nrf_stream_t stream) {
+    return bake(static_cast<const float*>(packed_teacher_h2), aabb_host, res_host, threshold, first_cell, n_cells, occ, workspace,
+                workspace_bytes, false, stream, true);
 }
 
 NRF_EXPORT int64_t nrf_occ_bake_vertices_workspace_bytes(int64_t n_cells) { return bake_workspace_bytes(n_cells, 1); }
