@@ -161,6 +161,17 @@ int nrf_mlp_backward_bf16x3(const float* packed, const void* packed_t_x3, const 
                             const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace, int64_t workspace_bytes,
                             float* grad_flat, nrf_stream_t stream);
 
+/* nrf_mlp_backward with the data-gradient chain on the two-term fp16 kernel (the weight-gradient GEMMs are the bf16x3
+ * ones).  Gradients are far below fp16's normal range, so the chain runs at a power-of-two loss scale chosen on the
+ * device from max |grad_raw| of the call and every dY row is unscaled (exactly) before it is stored: callers see
+ * ordinary fp32 gradients.  packed: nrf_pack_weights (head rows); packed_t_h2: nrf_pack_weights_transposed_fp16x2
+ * (nrf_packed_bwd_fp16x2_bytes() bytes).  Same workspace, acts / masks and gradient layout as nrf_mlp_backward. */
+int64_t nrf_packed_bwd_fp16x2_bytes(void);
+int nrf_pack_weights_transposed_fp16x2(const float* const* weights_host, void* packed_t_h2, nrf_stream_t stream);
+int nrf_mlp_backward_fp16x2(const float* packed, const void* packed_t_h2, const float* grad_raw, const float* acts,
+                            const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace, int64_t workspace_bytes,
+                            float* grad_flat, nrf_stream_t stream);
+
 /* ---- alpha compositing: volume_renderer.py:222-224, 236-265 / 291-334 --------------- */
 
 /* sigma = relu(raw[...,3]); rgb = sigmoid(raw[...,:3]); delta = diff(z), last = 1e10;

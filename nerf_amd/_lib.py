@@ -32,7 +32,7 @@ SYMBOLS = (
     "nrf_packed_bf16x3_bytes", "nrf_pack_weights_bf16x3", "nrf_mlp_forward_rays_bf16x3", "nrf_mlp_forward_points_bf16x3",
     "nrf_render_bf16x3",
     "nrf_packed_fp16x2_bytes", "nrf_pack_weights_fp16x2", "nrf_packed_fp16x2_status", "nrf_mlp_forward_rays_fp16x2", "nrf_mlp_forward_points_fp16x2",
-    "nrf_render_fp16x2", "nrf_mlp_forward_rays_train_fp16x2", "nrf_kilo_pack_weights_fp16x2", "nrf_kilo_forward_fp16x2", "nrf_occ_bake_fp16x2",
+    "nrf_render_fp16x2", "nrf_mlp_forward_rays_train_fp16x2", "nrf_kilo_pack_weights_fp16x2", "nrf_kilo_forward_fp16x2", "nrf_occ_bake_fp16x2", "nrf_packed_bwd_fp16x2_bytes", "nrf_pack_weights_transposed_fp16x2", "nrf_mlp_backward_fp16x2",
 )
 
 P = C.c_void_p
@@ -156,6 +156,12 @@ def lib() -> C.CDLL:
     L.nrf_pack_weights_transposed_bf16x3.restype = INT
     L.nrf_mlp_backward_bf16x3.argtypes = [P, P, P, P, P, I64, INT, P, I64, P, P]
     L.nrf_mlp_backward_bf16x3.restype = INT
+    L.nrf_packed_bwd_fp16x2_bytes.restype = I64
+    L.nrf_packed_bwd_fp16x2_bytes.argtypes = []
+    L.nrf_pack_weights_transposed_fp16x2.argtypes = [P, P, P]
+    L.nrf_pack_weights_transposed_fp16x2.restype = INT
+    L.nrf_mlp_backward_fp16x2.argtypes = [P, P, P, P, P, I64, INT, P, I64, P, P]
+    L.nrf_mlp_backward_fp16x2.restype = INT
     L.nrf_packed_bf16_bytes.restype = I64
     L.nrf_packed_bf16_bytes.argtypes = []
     L.nrf_pack_weights_bf16.restype = INT

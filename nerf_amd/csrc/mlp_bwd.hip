@@ -651,13 +651,14 @@ NRF_EXPORT int64_t nrf_mlp_backward_workspace_bytes(int64_t n_rays, int n_sample
     const int64_t t = nrf_mlp_train_tiles(n_rays, n_samples);
     if (t < 0) return t;
     const int64_t slices = wgrad_slices(t);
-    return nrf_mlp_dys_bytes(n_rays, n_samples) + slices * (256 * 320 + 256) * 4;
+    return nrf_mlp_dys_bytes(n_rays, n_samples) + slices * (256 * 320 + 256) * 4 + 256;   // + the fp16x2 chain's scale word
 }
 
 // packed_t_x3 != nullptr: the data-gradient chain on the three-term bf16 kernel (mlp_bf16x3.hip) instead of mlp_dgrad_kernel
+// packed_t_h2 != nullptr: the chain on the two-term fp16 kernel (mlp_fp16x2.hip); its weight-gradient GEMMs are the bf16x3 ones
 static int mlp_backward_impl(const float* packed, const float* packed_t, const void* packed_t_x3, const float* grad_raw,
                              const float* acts, const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
-                             int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream_) {
+                             int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream_, const void* packed_t_h2 = nullptr) {
     if (n_rays < 0 || n_samples <= 0 || n_samples % 32 != 0) return NRF_ERR_SHAPE;
     if (!packed || !packed_t || !grad_raw || !acts || !masks || !workspace || !grad_flat) return NRF_ERR_NULL;
     if (!nrf_aligned16(packed) || !nrf_aligned16(packed_t) || !nrf_aligned16(grad_raw) || !nrf_aligned16(workspace) ||
@@ -677,7 +678,10 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
     nrf_launch_begin();
-    if (packed_t_x3) {
+    if (packed_t_h2) {
+        unsigned* gmax = reinterpret_cast<unsigned*>(pbias + int64_t(slices) * 256);
+        if (const int rc = launch_dgrad_h2(packed, packed_t_h2, grad_raw, masks, n_points, dys, gmax, stream)) return rc;
+    } else if (packed_t_x3) {
         if (const int rc = launch_dgrad_x3(packed, packed_t_x3, grad_raw, masks, n_points, dys, stream)) return rc;
     } else {
         mlp_dgrad_kernel<<<dim3(unsigned(groups < cus ? groups : cus)), 256, 0, stream>>>(
@@ -709,7 +713,7 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     };
     const dim3 grid(slices);
     // pts_linears.0: dY0 x encoding
-    const bool x3 = packed_t_x3 != nullptr;   // the bf16x3 route: these GEMMs on the bf16 pipe with three-term operands
+    const bool x3 = packed_t_x3 != nullptr || packed_t_h2 != nullptr;   // the bf16x3 route: these GEMMs on the bf16 pipe with three-term operands
     if (x3) { if (const int rc = launch_wgrad_x3<8, 2>(job(0, 256, kActPe, 64, 0, 0), slices, stream)) return rc; }
     else wgrad_kernel<8, 2, false><<<grid, 512, 0, stream>>>(job(0, 256, kActPe, 64, 0, 0));
     reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 0);
@@ -755,4 +759,15 @@ NRF_EXPORT int nrf_mlp_backward_bf16x3(const float* packed, const void* packed_t
     // (the fp32 transposed stream is not read on this route: the forward pack stands in for its pointer checks)
     return mlp_backward_impl(packed, packed, packed_t_x3, grad_raw, acts, masks, n_rays, n_samples, workspace, workspace_bytes,
                              grad_flat, stream);
+}
+
+// nrf_mlp_backward with the data-gradient chain on the two-term fp16 kernel at a loss scale chosen on the device
+// (mlp_fp16x2.hip: mlp_dgrad_h2_kernel) and the weight-gradient GEMMs on the three-term bf16 kernels.
+NRF_EXPORT int nrf_mlp_backward_fp16x2(const float* packed, const void* packed_t_h2, const float* grad_raw, const float* acts,
+                                       const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
+                                       int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream) {
+    if (!packed_t_h2) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed_t_h2)) return NRF_ERR_ALIGN;
+    return mlp_backward_impl(packed, packed, nullptr, grad_raw, acts, masks, n_rays, n_samples, workspace, workspace_bytes,
+                             grad_flat, stream, packed_t_h2);
 }

@@ -54,7 +54,7 @@ __global__ void hpack_layer_kernel(XPackLayer p, unsigned* status) {   // one th
     if (idx >= xpack_total(p)) return;
     int step, lane, jj;
     const float v = xpack_fetch(p, idx, step, lane, jj);
-    if (!(fabsf(v) < kF16Limit)) atomicOr(status, 1u);   // outside fp16 (or not a number): the kernel will say so
+    if (status && !(fabsf(v) < kF16Limit)) atomicOr(status, 1u);   // outside fp16 (or not a number): the kernel will say so
     const _Float16 hi = (_Float16)v;                                   // round to nearest even
     const _Float16 lo = (_Float16)(__fmul_rn(__fsub_rn(v, (float)hi), kLoScale));
     unsigned short* d = p.dst + int64_t(step) * (kHStepBytes / 2) + lane * 8 + jj;
@@ -155,7 +155,7 @@ struct OpInH : OpInBase {
         return;
 #endif
         if (phase == 0) {
-            input<MODE>(y, blk, q, sa, sb);
+            input<MODE, MODE == kOpBwd>(y, blk, q, sa, sb);
             p0 = pk_f16(sa, sb);
             x[q / 4][0][q % 4] = p0;
         } else if (phase == 1) {
@@ -175,7 +175,7 @@ struct OpInH : OpInBase {
     template <int MODE>
     __device__ __forceinline__ void pair(const f32x16& y, u32x4 (&x)[2][2], int blk, int q) {
         float a, b;
-        input<MODE>(y, blk, q, a, b);
+        input<MODE, MODE == kOpBwd>(y, blk, q, a, b);
         unsigned hi, lo;
         split_pair_f16(a, b, hi, lo);
         track_max(ovf, a, b);
@@ -469,6 +469,126 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
 
+// ---- backward data-gradient chain on the same machinery (mlp_bf16x3.hip: mlp_dgrad_x3_kernel is the bf16x3 form) -------
+// d(input of layer l) = W_l^T . dY_l with the transposed weights as the two-term stream (views^T, feature^T, pts7^T ..
+// pts1^T; nrf_pack_weights_transposed_fp16x2).  Gradients are O(1e-6): far below fp16's normal range, where the split
+// would lose its bits.  So the chain runs at a LOSS SCALE 2^S, S chosen on the device from max |d raw| of the batch
+// (grad_max_kernel; 2^S max = 16: twelve binades of head room above, fourteen of normal range below) -- d raw is scaled
+// on load, every dY row is unscaled on its way to HBM (both exact: powers of two), so the wgrad GEMMs and everything
+// else see ordinary fp32 gradients.  A point whose scaled gradients still leave fp16's range gets NaN rows.
+__global__ void grad_max_kernel(const float4* __restrict__ g, int64_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const float4 v = g[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __restrict__ packed,   // fp32 pack: head rows
+                                                              const char* __restrict__ packed_t,  // two-term W^T stream
+                                                              const float4* __restrict__ graw, const unsigned* __restrict__ masks,
+                                                              int64_t n_points, int64_t n_groups, float* __restrict__ dys,
+                                                              const unsigned* __restrict__ gmax_bits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    {
+        const float4* src = reinterpret_cast<const float4*>(packed + kOffBias);
+        float4* dst = reinterpret_cast<float4*>(smem + kHLdsConstOff);
+        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+    }
+    // loss scale 2^S with 2^S * max |d raw| in [16, 32): S = 4 - exponent(max); max = 0, subnormal or not finite: S = 0
+    float scale = 1.f, unscale = 1.f;
+    {
+        const int e = int((*gmax_bits >> 23) & 0xffu);
+        if (e > 0 && e < 255) {
+            int S = 4 - (e - 127);
+            S = S > 100 ? 100 : S < -100 ? -100 : S;
+            scale = __uint_as_float(unsigned(127 + S) << 23), unscale = __uint_as_float(unsigned(127 - S) << 23);
+        }
+    }
+    __syncthreads();
+    const float* cst = reinterpret_cast<const float*>(smem + kHLdsConstOff);
+    const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
+    const float* rw = cst + (kOffRgbW - kOffBias) + h * 16;
+
+    HRing st;
+    hr_start(st, packed_t, smem, wave, lane, kXBwdChunks);
+
+    for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+        const int64_t tile = tg * 4 + wave;
+        int64_t pidx = tile * 32 + j;
+        const bool valid = pidx < n_points;
+        if (!valid) pidx = n_points - 1;
+        float4 g = graw[pidx];
+        if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned* mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+        float* drow = dys + tile * (int64_t(kDyRows) * 32) + 4 * h * 32 + j;
+        if (h == 0) {  // d(raw) as 4 rows for the head wgrad jobs (unscaled)
+            float* r = dys + tile * (int64_t(kDyRows) * 32) + kDyRaw * 32 + j;
+            r[0] = g.x, r[32] = g.y, r[64] = g.z, r[96] = g.w;
+        }
+        g.x *= scale, g.y *= scale, g.z *= scale, g.w *= scale;
+        u32x4 X[8][2][2];
+        f32x16 Y[8], Z[kHLead - 1], YL[kHLead];
+        // rgb_linear^T on the VALU (fp32): dYv = relu'(hv) * (W_rgb^T . d rgb), stored, and the input of views^T
+        {
+            const unsigned m0 = mrow[(8 * 4 + 0) * 64], m1 = mrow[(8 * 4 + 1) * 64];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
+                const f32x16 w1 = *reinterpret_cast<const f32x16*>(rw + 128 + kb * 32);
+                const f32x16 w2 = *reinterpret_cast<const f32x16*>(rw + 256 + kb * 32);
+                f32x16 v;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = fmaf(w2[t], g.z, fmaf(w1[t], g.y, w0[t] * g.x));
+                Y[kb] = mask16(v, ((kb < 2 ? m0 : m1) >> (16 * (kb & 1))) & 0xffffu);
+            }
+        }
+        // d feature = W_views[:, :256]^T . dYv: four k-blocks in (masked above: all-ones mask here; the split stores them
+        // as the dY rows of views_linears.0), eight blocks out
+        OpInH op{op_in(kActNone, aw, drow + kDyV * 32), 0.f, 0.f, 0.f, 0.f, 0u, 0.f};
+        op.kscale = unscale;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) op.m[w] = ~0u;
+        h2_hidden_layer<8, 0, kOpBwd, 4>(st, lane, nullptr, X, nullptr, Y, Z, YL, op);
+        // li = 0: d h7 = W_feature^T . d feature (no activation between feature_linear and views_linears: all-ones mask,
+        // stored as the dY rows of feature_linear); li = 1 .. 7: layer l = 8 - li, dY_l = relu'(h_l) * d h_l (+ the
+        // alpha_linear term for h7), d h_{l-1} = W_l^T . dY_l.  One body, run-time loop.
+        for (int li = 0; li <= 7; ++li) {
+            const int l = 8 - li;
+            op.save = drow + (li == 0 ? kDyFeat : l * 256) * 32;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) op.m[w] = li == 0 ? 0xffffffffu : mrow[(l * 4 + w) * 64];
+            op.dsig = li == 1 ? g.w : 0.f;                       // h7 also feeds alpha_linear
+            h2_hidden_layer<8, 0, kOpBwd>(st, lane, nullptr, X, nullptr, Y, Z, YL, op);
+        }
+        {   // dY_0 = relu'(h_0) * d h_0 (the encoding needs no gradient: the chain ends here)
+            float ovf = op.ovf;
+            ovf = fmaxf(ovf, __shfl_xor(ovf, 32));
+            const float out_scale = ovf < kF16Limit ? unscale : __builtin_nanf("");   // a point that left the range says so
+            OpBwdMask last;
+            last.dst = drow;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) last.m[w] = mrow[w * 64];
+            last.aw = aw;
+            last.dsig = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x16 y = Y[i];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) y[t] *= out_scale;
+                (void)last(i, y);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+}
+
 int launch_h2(const void* packed, const float* a0, const float* a1, const float* z, int64_t z_stride, int tiles_per_ray,
               int rays_mode, int64_t n_points, float* raw, hipStream_t stream, float* acts = nullptr, unsigned* masks = nullptr) {
     const int64_t tiles = (n_points + 31) / 32;
@@ -499,6 +619,52 @@ int launch_h2(const void* packed, const float* a0, const float* a1, const float*
 }
 
 }  // namespace
+
+// nrf_mlp_backward_fp16x2 (mlp_bwd.hip) calls this in place of mlp_dgrad_kernel; gmax: one zeroed-here word of workspace
+int launch_dgrad_h2(const float* packed, const void* packed_t, const float* grad_raw, const unsigned* masks, int64_t n_points,
+                    float* dys, unsigned* gmax, hipStream_t stream) {
+    const int64_t groups = (n_points / 32 + 3) / 4;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    static bool attr_set[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kHLdsBytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    if (hipMemsetAsync(gmax, 0, 4, stream) != hipSuccess) return NRF_ERR_RUNTIME;
+    grad_max_kernel<<<dim3(unsigned(cus)), 256, 0, stream>>>(reinterpret_cast<const float4*>(grad_raw), n_points, gmax);
+    mlp_dgrad_h2_kernel<<<dim3(unsigned(groups < cus ? groups : cus)), 256, kHLdsBytes, stream>>>(
+        packed, static_cast<const char*>(packed_t), reinterpret_cast<const float4*>(grad_raw), masks, n_points, groups, dys, gmax);
+    return NRF_OK;
+}
+
+NRF_EXPORT int64_t nrf_packed_bwd_fp16x2_bytes(void) { return int64_t(kXBwdSteps) * kHStepBytes; }
+
+// The backward chain's stream in the order it is consumed (mlp_bf16x3.hip: nrf_pack_weights_transposed_bf16x3), two fp16
+// terms per weight.  (Out-of-range weights are reported by the forward packer, nrf_packed_fp16x2_status.)
+NRF_EXPORT int nrf_pack_weights_transposed_fp16x2(const float* const* w, void* packed_t, nrf_stream_t stream_) {
+    if (!w || !packed_t) return NRF_ERR_NULL;
+    for (int i = 0; i < NRF_NUM_LAYERS; ++i)
+        if (!w[i]) return NRF_ERR_NULL;
+    if (!nrf_aligned16(packed_t)) return NRF_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned short* base = static_cast<unsigned short*>(packed_t);
+    nrf_launch_begin();
+    int step = 0;
+    auto launch = [&](const float* W, int ldw, int in_blocks, int col0) {   // in_blocks = k-blocks = rows of W / 32
+        XPackLayer p{W, base + int64_t(step) * (kHStepBytes / 2), ldw, 8, 0, in_blocks, 0, 0, 0, 0, col0, 0, kHLead, 1};
+        const int total = 8 * in_blocks * 2 * 512;
+        hpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p, nullptr);
+        step += 8 * in_blocks * 2;
+    };
+    launch(w[10], 283, 4, 0);   // views^T: 128 outputs of views_linears.0 contracted, 256 feature columns out
+    launch(w[8], 256, 8, 0);    // feature^T
+    for (int l = 7; l >= 1; --l) launch(w[l], l == 5 ? 319 : 256, 8, l == 5 ? 63 : 0);
+    return nrf_launch_status();
+}
 
 NRF_EXPORT int64_t nrf_packed_fp16x2_bytes(void) { return kHStatusOff + 16; }
 

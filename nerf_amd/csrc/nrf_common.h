@@ -120,3 +120,6 @@ __host__ __device__ inline int pe_col(int n, int h, int L) {
 // mlp_bf16x3.hip, for nrf_mlp_backward_bf16x3 (mlp_bwd.hip): the data-gradient chain on the three-term bf16 kernel
 int launch_dgrad_x3(const float* packed, const void* packed_t, const float* grad_raw, const unsigned* masks, int64_t n_points,
                     float* dys, hipStream_t stream);
+// mlp_fp16x2.hip, for nrf_mlp_backward_fp16x2: the same chain on the two-term fp16 kernel at a device-chosen loss scale
+int launch_dgrad_h2(const float* packed, const void* packed_t, const float* grad_raw, const unsigned* masks, int64_t n_points,
+                    float* dys, unsigned* gmax, hipStream_t stream);

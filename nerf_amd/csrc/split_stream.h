@@ -104,12 +104,13 @@ struct OpInBase {
     // the training forward saved (mlp_bwd.hip: OpBwdMask) and written to `save` as the dY rows of the wgrad GEMMs
     unsigned m[4];
     float dsig;
-    template <int MODE>
+    float kscale;      // SCALED stores (the fp16x2 backward chain runs at a power-of-two loss scale): saved = value * kscale
+    template <int MODE, bool SCALED = false>
     __device__ __forceinline__ void keep(int blk, int q, float a, float b) {
         if (MODE == kOpFwd) return;
         const int t0 = 2 * q, t1 = 2 * q + 1;
-        save[(32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32] = a;
-        save[(32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32] = b;
+        save[(32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32] = SCALED ? a * kscale : a;
+        save[(32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32] = SCALED ? b * kscale : b;
         if (MODE == kOpFwdSave && msave) {
             if (q == 0) mcur = 0u;
             mcur |= ((a > 0.f ? 1u : 0u) << t0) | ((b > 0.f ? 1u : 0u) << t1);
@@ -127,7 +128,7 @@ struct OpInBase {
             for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], hx[t], sigma);
         }
     }
-    template <int MODE>
+    template <int MODE, bool SCALED = false>
     __device__ __forceinline__ void input(const f32x16& y, int blk, int q, float& a, float& b) {
         if (MODE == kOpBwd) {
             const float2 w = *reinterpret_cast<const float2*>(aw + blk * 32 + 2 * q);
@@ -138,11 +139,11 @@ struct OpInBase {
             const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
             a = __int_as_float(b0 > lim ? b0 : lim), b = __int_as_float(b1 > lim ? b1 : lim);
         }
-        keep<MODE>(blk, q, a, b);
+        keep<MODE, SCALED>(blk, q, a, b);
     }
 };
 __device__ __forceinline__ OpInBase op_in(int lim, const float* aw, float* save = nullptr) {
-    return OpInBase{lim, false, aw, 0.f, save, nullptr, 0u, 0u, {0u, 0u, 0u, 0u}, 0.f};
+    return OpInBase{lim, false, aw, 0.f, save, nullptr, 0u, 0u, {0u, 0u, 0u, 0u}, 0.f, 1.f};
 }
 
 }  // namespace

@@ -323,6 +323,18 @@ def pack_weights_transposed_bf16x3(weights, out: torch.Tensor | None = None) -> 
     return out
 
 
+def pack_weights_transposed_fp16x2(weights, out: torch.Tensor | None = None) -> torch.Tensor:
+    """The backward chain's weights as the two-term fp16 stream (nrf_pack_weights_transposed_fp16x2, uint8 buffer)."""
+    ws = [_f32(w.detach(), "weight") for w in weights]
+    dev = ws[0].device
+    if out is None:
+        out = torch.empty(int(lib().nrf_packed_bwd_fp16x2_bytes()), dtype=torch.uint8, device=dev)
+    wp = (C.c_void_p * 12)(*[w.data_ptr() for w in ws])
+    with torch.cuda.device(dev):
+        check(lib().nrf_pack_weights_transposed_fp16x2(wp, _ptr(out), _stream(out)), "nrf_pack_weights_transposed_fp16x2")
+    return out
+
+
 def mlp_forward_rays_train(packed, rays_o, rays_d, z, kind: str = "fp32"):
     """-> (raw (R,S,4), acts, masks): the saved tensors are opaque buffers for mlp_backward.  ``kind``: "fp32"
     (``packed`` from pack_weights) or "bf16x3" (``packed`` from pack_weights_bf16x3: the forward on the three-term
@@ -362,7 +374,8 @@ def composite_backward(raw, z, white_bkgd, g_rgb=None, g_depth=None, g_acc=None)
 def mlp_backward(packed, packed_t, g_raw, acts, masks, workspace: torch.Tensor | None = None,
                  out: torch.Tensor | None = None, kind: str = "fp32") -> torch.Tensor:
     """-> flat gradient (595,844,) of one model in state-dict order (weight then bias per layer).  ``kind`` "bf16x3":
-    ``packed_t`` from pack_weights_transposed_bf16x3, the data-gradient chain on the three-term bf16 kernel."""
+    ``packed_t`` from pack_weights_transposed_bf16x3, the data-gradient chain on the three-term bf16 kernel; "fp16x2":
+    pack_weights_transposed_fp16x2, the chain on the two-term fp16 kernel at a device-chosen loss scale."""
     g_raw = _f32(g_raw, "g_raw")
     R, S = g_raw.shape[0], g_raw.shape[1]
     dev = g_raw.device
@@ -371,12 +384,12 @@ def mlp_backward(packed, packed_t, g_raw, acts, masks, workspace: torch.Tensor |
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     flat = torch.zeros(model_param_floats(), dtype=torch.float32, device=dev) if out is None else out
-    if kind not in ("fp32", "bf16x3"):
-        raise ValueError(f"kind {kind!r}: expected 'fp32' or 'bf16x3'")
-    fn = L.nrf_mlp_backward if kind == "fp32" else L.nrf_mlp_backward_bf16x3
+    if kind not in ("fp32", "bf16x3", "fp16x2"):
+        raise ValueError(f"kind {kind!r}: expected 'fp32', 'bf16x3' or 'fp16x2'")
+    fn = {"fp32": L.nrf_mlp_backward, "bf16x3": L.nrf_mlp_backward_bf16x3, "fp16x2": L.nrf_mlp_backward_fp16x2}[kind]
     with torch.cuda.device(dev):
         check(fn(_ptr(packed), _ptr(packed_t), _ptr(g_raw), _ptr(acts), _ptr(masks), R, S, _ptr(workspace),
-                 workspace.numel(), _ptr(flat), _stream(flat)), "nrf_mlp_backward" + ("" if kind == "fp32" else "_bf16x3"))
+                 workspace.numel(), _ptr(flat), _stream(flat)), "nrf_mlp_backward" + ("" if kind == "fp32" else "_" + kind))
     return flat
 
 

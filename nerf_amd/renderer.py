@@ -54,10 +54,10 @@ class _RenderTrainFn(torch.autograd.Function):
         white = renderer.white_bkgd > 0
         # mlp_dtype "bf16x3": both forward passes, the data-gradient chain and the weight-gradient GEMMs on the three-term
         # bf16 kernels (fp32-class); the fp32 pack still supplies the head rows of the backward
-        # "fp16x2": the forward passes on the two-term fp16 kernel, the backward as "bf16x3" (bf16 has fp32's
-        # exponent range: gradients need no loss scale)
+        # "fp16x2": forward passes and the data-gradient chain on the two-term fp16 kernels (the chain at a
+        # loss scale it picks itself), weight-gradient GEMMs on the bf16x3 kernels
         kind = renderer.mlp_dtype
-        bkind = "fp32" if kind == "fp32" else "bf16x3"
+        bkind = kind
         pc, pc_t = renderer._packed_model("model", dev), renderer._packed_model_t("model", dev, bkind)
         pf, pf_t = renderer._packed_model("model_fine", dev), renderer._packed_model_t("model_fine", dev, bkind)
         fc = pc if kind == "fp32" else renderer._packed_model("model", dev, kind)
@@ -258,7 +258,8 @@ class Renderer(nn.Module):
         hit = self._packed_t.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
-        pack = ops.pack_weights_transposed if kind == "fp32" else ops.pack_weights_transposed_bf16x3
+        pack = {"fp32": ops.pack_weights_transposed, "bf16x3": ops.pack_weights_transposed_bf16x3,
+                "fp16x2": ops.pack_weights_transposed_fp16x2}[kind]
         buf = pack(params[0::2], out=hit[1] if hit is not None else None)
         self._packed_t[slot] = (key, buf)
         return buf

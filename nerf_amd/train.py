@@ -30,15 +30,18 @@ def exponential_lr(base_lr: float, epoch: int, decay_epochs: int = 500, gamma: f
 
 class TrainStep:
     def __init__(self, net, device, near=2.0, far=6.0, n_coarse=64, n_importance=128, white_bkgd=True,
-                 lr=5e-4, clip_value=40.0, process_group=None, forward_dtype="fp32"):
+                 lr=5e-4, clip_value=40.0, process_group=None, forward_dtype="fp32", backward_dtype=None):
         """``forward_dtype``: "fp32" (the fp32 MFMA kernels), "bf16x3" -- both forward passes, the backward's
         data-gradient chain and the weight-gradient GEMMs on the three-term bf16 kernels (fp32-class: DESIGN 3.7; the
         forward saves the same activations) -- or "fp16x2": the two forward passes on the two-term fp16 kernel
-        (same saved activations), the backward as in "bf16x3" (gradients would need a loss scale to sit
-        in fp16's range; bf16's exponent is fp32's)."""
+        (same saved activations) and the backward's data-gradient chain on it too, at a power-of-two loss
+        scale the kernel picks from the batch's largest |d raw| (weight-gradient GEMMs on the bf16x3 kernels).
+        ``backward_dtype``: "bf16x3" or "fp16x2" to choose the chain's kernel separately (default: the forward's)."""
         if forward_dtype not in ("fp32", "bf16x3", "fp16x2"):
             raise ValueError(f"forward_dtype {forward_dtype!r}: expected 'fp32', 'bf16x3' or 'fp16x2'")
-        self.backward_dtype = "fp32" if forward_dtype == "fp32" else "bf16x3"
+        self.backward_dtype = backward_dtype or forward_dtype
+        if self.backward_dtype not in ("fp32", "bf16x3", "fp16x2") or (self.backward_dtype == "fp32") != (forward_dtype == "fp32"):
+            raise ValueError(f"backward_dtype {backward_dtype!r} with forward_dtype {forward_dtype!r}")
         self.forward_dtype = forward_dtype
         self.net = net
         self.device = torch.device(device)
@@ -85,6 +88,8 @@ class TrainStep:
                 self._packed_x3[k] = ops.pack_weights_fp16x2(ws, bs, out=self._packed_x3[k], check_range=False)  # -> NaN loss
             if self.backward_dtype == "bf16x3":
                 self._packed_t[k] = ops.pack_weights_transposed_bf16x3(ws, out=self._packed_t[k])
+            elif self.backward_dtype == "fp16x2":
+                self._packed_t[k] = ops.pack_weights_transposed_fp16x2(ws, out=self._packed_t[k])
             else:
                 self._packed_t[k] = ops.pack_weights_transposed(ws, out=self._packed_t[k])
 
