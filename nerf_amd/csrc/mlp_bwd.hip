@@ -714,7 +714,7 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     const dim3 grid(slices);
     // pts_linears.0: dY0 x encoding
     const bool x3 = packed_t_x3 != nullptr || packed_t_h2 != nullptr;   // the bf16x3 route: these GEMMs on the bf16 pipe with three-term operands
-    if (x3) { if (const int rc = launch_wgrad_x3<8, 2>(job(0, 256, kActPe, 64, 0, 0), slices, stream)) return rc; }
+    if (x3) { if (const int rc = launch_wgrad_x3p<8, 2>(job(0, 256, kActPe, 64, 0, 0), slices, stream)) return rc; }
     else wgrad_kernel<8, 2, false><<<grid, 512, 0, stream>>>(job(0, 256, kActPe, 64, 0, 0));
     reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 0);
     for (int l = 1; l <= 7; ++l) {
@@ -733,7 +733,7 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     else wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0));
     reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, 8);
     // views_linears.0: dYv x cat([feature, dir encoding]) (network.py:63)
-    if (x3) { if (const int rc = launch_wgrad_x3<4, 9>(job(kDyV, 128, kActFeat, 256, kActDpe, 32), slices, stream)) return rc; }
+    if (x3) { if (const int rc = launch_wgrad_x3p<4, 9>(job(kDyV, 128, kActFeat, 256, kActDpe, 32), slices, stream)) return rc; }
     else wgrad_kernel<4, 9, false><<<grid, 256, 0, stream>>>(job(kDyV, 128, kActFeat, 256, kActDpe, 32));
     reduce(128, 288, 128, ColMap{{256, 32}, {0, 4}, {0, 256}}, 10);
     // alpha_linear: d sigma (raw row 3) x h7;  rgb_linear: d rgb (raw rows 0..2) x hv
