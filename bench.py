@@ -226,7 +226,7 @@ def train_bench(args, net, dev, rank, world, dist):
     # weight-gradient GEMMs) on the three-term bf16 kernels (fp32-class, same saved activations); the alpha / rgb head
     # rows stay on the fp32 MFMA / VALU.  --dtype fp32: everything on the fp32 MFMA.
     x3 = args.dtype in ("bf16x3", "fp16x2")
-    h2 = args.dtype == "fp16x2"                  # forward passes and data-gradient chain on the fp16x2 kernels, GEMMs on bf16x3
+    h2 = args.dtype == "fp16x2"                  # forward passes, data-gradient chain and weight-gradient GEMMs on the fp16x2 kernels
     ts = TrainStep(net, dev, forward_dtype=args.dtype if x3 else "fp32")
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
@@ -267,26 +267,25 @@ def train_bench(args, net, dev, rank, world, dist):
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         flop = 3.0 * R * (N_COARSE + N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT   # fwd + dgrad + wgrad, SURVEY 8d
-        peak = BF16_MFMA_PEAK_TFLOPS / 4 if h2 else BF16_MFMA_PEAK_TFLOPS / 6 if x3 else FP32_MFMA_PEAK_TFLOPS
+        peak = BF16_MFMA_PEAK_TFLOPS / 3 if h2 else BF16_MFMA_PEAK_TFLOPS / 6 if x3 else FP32_MFMA_PEAK_TFLOPS
         line = {
             "metric": "training rays/sec (fwd+bwd+Adam step, 64 coarse + 128 fine samples/ray)",
             "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (matrix work: forward passes and data-gradient chain fp16x2 = f32 operands as 2 fp16 terms, 3 MFMAs per "
-                     "product, the chain at a power-of-two loss scale; weight-gradient GEMMs bf16x3 = 3 bf16 terms, 6 MFMAs per "
-                     "product; f32 accumulate)" if h2 else
+            "dtype": "f32 (matrix work fp16x2: f32 operands as 2 fp16 terms = 22 significand bits, 3 fp16 MFMAs per product, f32 "
+                     "accumulate; the backward at power-of-two scales chosen on the device and undone exactly)" if h2 else
                      "f32 (matrix work bf16x3: f32 operands as 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate)" if x3 else "f32",
             "data": "synthetic (random pixels of orbit views, random gt, random-init weights)",
             "config": {"workload": "BASELINE configs[2]: NeRF training step, %d-ray batch per rank, fwd+bwd with Adam, "
                                    "data-parallel RCCL all-reduce" % R, "rays_per_rank": R, "perturb": 1,
                        "forward_kernel": "mlp_fp16x2_kernel<save>" if h2 else "mlp_bf16x3_kernel<save>" if x3 else "mlp_fwd_kernel<save>"},
-            "roofline": {"kernel": "whole step (%s)" % ("mlp_fp16x2<save> + mlp_dgrad_h2 + wgrad_x3 GEMMs" if h2 else
+            "roofline": {"kernel": "whole step (%s)" % ("mlp_fp16x2<save> + mlp_dgrad_h2 + wgrad_h2p GEMMs" if h2 else
                                                         "mlp_bf16x3<save> + mlp_dgrad_x3 + wgrad_x3 GEMMs" if x3 else "mlp_fwd<save> + mlp_dgrad + wgrad GEMMs"),
                          "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12,
                          "peak": peak, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / peak,
                          "traffic": None,
                          "note": "algorithmic FLOPs of the step / wall time of the step, not one kernel; peak = " +
-                                 ("matrix peak / 4 (two thirds of the FLOPs at three MFMAs per fp32 product, one third at six); the "
+                                 ("fp16 MFMA / 3 (three MFMAs per fp32 product); the "
                                   "step also moves ~42 GB of saved activations and dY rows through HBM (DESIGN 3.5)" if h2 else
                                   "bf16 MFMA / 6 (six MFMAs per fp32 product); the step also moves ~42 GB of saved activations "
                                   "and dY rows through HBM (DESIGN 3.5)" if x3 else "fp32 MFMA")},

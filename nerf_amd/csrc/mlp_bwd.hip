@@ -17,6 +17,7 @@
 //          reference's (out, in) state-dict layout, undoing the kernel's encoding-slot order.
 #include "mlp_chain.h"
 #include "split3.h"
+#include "split2h.h"
 
 namespace {
 
@@ -129,6 +130,8 @@ struct WgradJob {
     int tiles_per_slice;
     float* partial;      // [slice][M][K]
     float* pbias;        // [slice][M]
+    const unsigned* scale_words;   // fp16x2 GEMMs: the chain's scale block (mlp_fp16x2.hip: kGmax*), else nullptr
+    int scale_word;                // ... and the word of this job's dY row set
 };
 
 constexpr int kLdsRow = 33;  // padded tile row: feature-on-lane operand reads hit 32 distinct banks
@@ -544,6 +547,189 @@ static int launch_wgrad_x3p(const WgradJob& job, unsigned slices, hipStream_t st
     return NRF_OK;
 }
 
+// wgrad_x3p_kernel with two fp16 terms per operand (split2h.h) and THREE MFMAs per product into ONE accumulator.  The
+// second accumulator of the forward kernels would cost KB more blocks here; instead the dY operand, whose scale is ours
+// to choose, is multiplied by 2^T so that its row set's largest entry (left by mlp_dgrad_h2_kernel in the chain's scale
+// block) lands in [2048, 4096), and its planes are hi, hi * 2^-11 and the UNSCALED low term: a_hi.b_hi, (a_hi 2^-11).b_lo'
+// and a_lo.b_hi then share one scale.  The two small planes go subnormal for entries below 2^-15 of the maximum, whose
+// absolute error (2^-25 of the scaled operand) is 2^-37 of the largest term; X keeps the forward's hi | lo * 2^11.  The
+// sums are unscaled (exactly) when the partials are written.  LDS: [stage][dY hi | hs | lo | X hi | lo'][row][16 points].
+template <int NW, int KB>
+__global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
+    constexpr int NT = NW * 64;
+    constexpr int M = 32 * NW, K = 32 * KB;
+    constexpr int kPA = M * kX3HalfRow, kPB = K * kX3HalfRow, kStage = 3 * kPA + 2 * kPB;
+    extern __shared__ __attribute__((aligned(16))) char s_x3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5, q = tid & 3, r0row = tid >> 2;
+    const int slice = blockIdx.x;
+    const int64_t t0 = int64_t(slice) * job.tiles_per_slice;
+    int64_t t1 = t0 + job.tiles_per_slice;
+    if (t1 > job.n_tiles) t1 = job.n_tiles;
+    const int64_t n_half = t1 > t0 ? 2 * (t1 - t0) : 0;   // half-steps of this slice
+    // stored dY = chain value * 2^-S; chain maximum of the row set in scale_words[scale_word]
+    int T = 0;
+    {
+        const unsigned row_max = job.scale_words[job.scale_word];
+        if (((row_max >> 23) & 0xffu) != 0)
+            T = scale_exponent(job.scale_words[0], kChainScaleTarget) + scale_exponent(row_max, kWgradScaleTarget);
+        T = T > 120 ? 120 : T < -120 ? -120 : T;
+    }
+    const float sc = exp2i(T), unsc = exp2i(-T);
+
+    f32x16 acc[KB];
+#pragma unroll
+    for (int a = 0; a < KB; ++a)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
+
+    constexpr int NAh = M * 4 / NT;                 // float4 pieces of dY per thread and half
+    constexpr int NBh = (K * 4 + NT - 1) / NT;      // ... of X
+    static_assert(M * 4 % NT == 0 && NAh >= 1, "whole dY pieces per thread");
+    constexpr int NI = NAh + NBh;                   // items per half
+    float4 reg[2][NI];                              // [half][item]: dY items first
+    float bsum[NAh];   // lanes with q == 0: row sum of dY row r0row + (NT / 4) * j
+#pragma unroll
+    for (int n = 0; n < NAh; ++n) bsum[n] = 0.f;
+
+    auto load_half = [&](int64_t hs, float4 (&r)[NI]) {   // hs = half-step index inside the slice
+        const int64_t tile = t0 + (hs >> 1);
+        const int h = int(hs & 1);
+        const float* pa = job.a + (tile * job.a_stride + job.a_row0) * 32 + (4 * h + q) * 4;
+#pragma unroll
+        for (int j = 0; j < NAh; ++j) {
+            const int row = r0row + (NT / 4) * j;
+            r[j] = row < job.a_rows ? *reinterpret_cast<const float4*>(pa + row * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* xb = job.x + tile * job.x_stride * 32 + (4 * h + q) * 4;
+#pragma unroll
+        for (int j = 0; j < NBh; ++j) {
+            const int row = r0row + (NT / 4) * j;
+            if (row < K) {
+                const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
+                r[NAh + j] = *reinterpret_cast<const float4*>(xb + src_row * 32);
+            }
+        }
+    };
+    // sub-slice w of the split of one half (items x 2 pairs x 3 phases); the item's 8-byte stores ride on its last one
+    unsigned p1[3], p2[3];   // the planes' words of the item's first / second pair
+    float sx, sy, r0, r1;
+    auto pair_phase = [&](bool is_a, float x, float y, int phase, unsigned (&p)[3]) {
+        if (phase == 0) {
+            sx = is_a ? x * sc : x, sy = is_a ? y * sc : y;
+            p[0] = pk_f16(sx, sy);
+        } else if (phase == 1) {
+            r0 = f16_residual_lo(sx, p[0]), r1 = f16_residual_hi(sy, p[0]);
+            if (is_a) {
+                const f16x2 hs = __builtin_bit_cast(f16x2, p[0]) * (f16x2){(_Float16)kLoUnscale, (_Float16)kLoUnscale};
+                p[1] = __builtin_bit_cast(unsigned, hs);
+            }
+        } else {
+            if (is_a) p[2] = pk_f16(r0, r1);
+            else p[1] = pk_f16_scaled(r0, r1);
+        }
+    };
+    auto split_sub = [&](char* stage, float4 (&r)[NI], int w) {
+        const int item = w / 6, ph = w % 6;
+        const bool is_a = item < NAh;
+        const int row = r0row + (NT / 4) * (is_a ? item : item - NAh);
+        if (!is_a && row >= K) return;
+        const float4 v = r[item];
+        if (ph < 3) pair_phase(is_a, v.x, v.y, ph, p1);
+        else pair_phase(is_a, v.z, v.w, ph - 3, p2);
+        if (ph == 5) {
+            char* d = stage + (is_a ? 0 : 3 * kPA) + row * kX3HalfRow + q * 8;
+            const int plane = is_a ? kPA : kPB;
+            *reinterpret_cast<uint2*>(d) = make_uint2(p1[0], p2[0]);
+            *reinterpret_cast<uint2*>(d + plane) = make_uint2(p1[1], p2[1]);
+            if (is_a) {
+                *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2(p1[2], p2[2]);
+                // bias gradient: the row's 16 points of this half = the four lanes of a quad
+                float t = (v.x + v.y) + (v.z + v.w);
+                t += nrf_dpp<0xB1>(0.f, t);   // quad_perm [1, 0, 3, 2]
+                t += nrf_dpp<0x4E>(0.f, t);   // quad_perm [2, 3, 0, 1]
+                bsum[item] += t;
+            }
+        }
+    };
+    constexpr int W = NI * 6;          // sub-slices per half
+    constexpr int S = 3 * KB;          // MFMA gaps per half
+
+    // one half-step: MFMAs on stage `cur` (KB groups of three), the split of the next half into the other stage in the gaps
+    auto half_step = [&](const char* cur, char* nxt, float4 (&rn)[NI], bool do_split) {
+        const char* pa = cur + (wave * 32 + i) * kX3HalfRow + 16 * kh;
+        const char* pb = cur + 3 * kPA + i * kX3HalfRow + 16 * kh;
+        auto frag_b = [&](int k, int t) { return *reinterpret_cast<const u32x4*>(pb + t * kPB + k * 32 * kX3HalfRow); };
+        u32x4 a[3], b[2][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const u32x4*>(pa + t * kPA);
+        b[0][0] = frag_b(0, 0), b[0][1] = frag_b(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int c = k & 1;
+            const bool more = k + 1 < KB;
+#define NRF_WGH_GAP(m, ta, tb, RD)                                                      \
+    acc[k] = NRF_MFMA_F16(a[ta], b[c][tb], acc[k]);                                     \
+    RD;                                                                                 \
+    if (do_split) {                                                                     \
+        _Pragma("unroll") for (int w = ((k * 3 + m) * W) / S; w < ((k * 3 + m + 1) * W) / S; ++w) split_sub(nxt, rn, w); \
+    }                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+            NRF_WGH_GAP(0, 2, 0, if (more) b[c ^ 1][0] = frag_b(k + 1, 0))   // small terms first: a_lo . b_hi
+            NRF_WGH_GAP(1, 1, 1, if (more) b[c ^ 1][1] = frag_b(k + 1, 1))   // (a_hi 2^-11) . b_lo'
+            NRF_WGH_GAP(2, 0, 0, (void)0)                                    // a_hi . b_hi
+#undef NRF_WGH_GAP
+        }
+    };
+
+    if (n_half > 0) {
+        char* st0 = s_x3;
+        char* st1 = s_x3 + kStage;
+        load_half(0, reg[0]);
+        load_half(1, reg[1]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) split_sub(st0, reg[0], w);   // the first half: nothing to hide it under
+        __syncthreads();
+        for (int64_t hs = 0; hs < n_half; hs += 2) {
+            if (hs + 2 < n_half) load_half(hs + 2, reg[0]);
+            half_step(st0, st1, reg[1], true);
+            __syncthreads();
+            const bool more = hs + 2 < n_half;
+            if (hs + 3 < n_half) load_half(hs + 3, reg[1]);
+            half_step(st1, st0, reg[0], more);
+            __syncthreads();
+        }
+    }
+    float* out = job.partial + int64_t(slice) * M * K;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) out[int64_t(wave * 32 + acc_row(t, kh)) * K + k * 32 + i] = acc[k][t] * unsc;
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int n = 0; n < NAh; ++n) job.pbias[int64_t(slice) * M + r0row + (NT / 4) * n] = bsum[n];
+    }
+}
+
+template <int NW, int KB>
+static int launch_wgrad_h2p(const WgradJob& job, unsigned slices, hipStream_t stream) {
+    constexpr int bytes = 2 * (3 * 32 * NW + 2 * 32 * KB) * kX3HalfRow;
+    static_assert(bytes <= 160 * 1024, "LDS budget");
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_h2p_kernel<NW, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                bytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    wgrad_h2p_kernel<NW, KB><<<dim3(slices), NW * 64, bytes, stream>>>(job);
+    return NRF_OK;
+}
+
 template <int NW, int KB>
 static int launch_wgrad_x3(const WgradJob& job, unsigned slices, hipStream_t stream) {
     constexpr int bytes = 3 * (32 * NW + 32 * KB) * kX3Row;
@@ -678,8 +864,8 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
     nrf_launch_begin();
+    unsigned* gmax = reinterpret_cast<unsigned*>(pbias + int64_t(slices) * 256);   // the fp16x2 chain's scale block
     if (packed_t_h2) {
-        unsigned* gmax = reinterpret_cast<unsigned*>(pbias + int64_t(slices) * 256);
         if (const int rc = launch_dgrad_h2(packed, packed_t_h2, grad_raw, masks, n_points, dys, gmax, stream)) return rc;
     } else if (packed_t_x3) {
         if (const int rc = launch_dgrad_x3(packed, packed_t_x3, grad_raw, masks, n_points, dys, stream)) return rc;
@@ -697,8 +883,9 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
         o += kLayerOut[l];
     }
     const int tps = int((n_tiles + slices - 1) / slices);
-    auto job = [&](int a_row0, int a_rows, int xr0, int xn0, int xr1, int xn1) {
+    auto job = [&](int a_row0, int a_rows, int xr0, int xn0, int xr1, int xn1, int scale_word = 0) {
         WgradJob j;
+        j.scale_words = gmax, j.scale_word = scale_word;
         j.a = dys, j.x = acts, j.a_stride = kDyRows, j.x_stride = kActRows;
         j.a_row0 = a_row0, j.a_rows = a_rows;
         j.x_row0[0] = xr0, j.x_rows[0] = xn0, j.x_row0[1] = xr1, j.x_rows[1] = xn1;
@@ -713,27 +900,33 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     };
     const dim3 grid(slices);
     // pts_linears.0: dY0 x encoding
-    const bool x3 = packed_t_x3 != nullptr || packed_t_h2 != nullptr;   // the bf16x3 route: these GEMMs on the bf16 pipe with three-term operands
-    if (x3) { if (const int rc = launch_wgrad_x3p<8, 2>(job(0, 256, kActPe, 64, 0, 0), slices, stream)) return rc; }
+    const bool h2 = packed_t_h2 != nullptr;   // the fp16x2 route: the four wide GEMMs on wgrad_h2p_kernel, scaled per row set
+    const bool x3 = packed_t_x3 != nullptr;   // the bf16x3 route: these GEMMs on the bf16 pipe with three-term operands
+    if (h2) { if (const int rc = launch_wgrad_h2p<8, 2>(job(0, 256, kActPe, 64, 0, 0, kGmaxLayer0), slices, stream)) return rc; }
+    else if (x3) { if (const int rc = launch_wgrad_x3p<8, 2>(job(0, 256, kActPe, 64, 0, 0), slices, stream)) return rc; }
     else wgrad_kernel<8, 2, false><<<grid, 512, 0, stream>>>(job(0, 256, kActPe, 64, 0, 0));
     reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 0);
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {  // cat([encoding, h4]) (network.py:58)
-            if (x3) { if (const int rc = launch_wgrad_x3<8, 10>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256), slices, stream)) return rc; }
+            if (h2) { if (const int rc = launch_wgrad_h2p<8, 10>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256, kGmaxLayer0 + 5), slices, stream)) return rc; }
+            else if (x3) { if (const int rc = launch_wgrad_x3<8, 10>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256), slices, stream)) return rc; }
             else wgrad_kernel<8, 10, false><<<grid, 512, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
             reduce(256, 320, 256, ColMap{{64, 256}, {10, 0}, {0, 63}}, 5);
         } else {
-            if (x3) { if (const int rc = launch_wgrad_x3p<8, 8>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0), slices, stream)) return rc; }
+            if (h2) { if (const int rc = launch_wgrad_h2p<8, 8>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0, kGmaxLayer0 + l), slices, stream)) return rc; }
+            else if (x3) { if (const int rc = launch_wgrad_x3p<8, 8>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0), slices, stream)) return rc; }
             else wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0));
             reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, l);
         }
     }
     // feature_linear: d feature x h7
-    if (x3) { if (const int rc = launch_wgrad_x3p<8, 8>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0), slices, stream)) return rc; }
+    if (h2) { if (const int rc = launch_wgrad_h2p<8, 8>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0, kGmaxFeat), slices, stream)) return rc; }
+    else if (x3) { if (const int rc = launch_wgrad_x3p<8, 8>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0), slices, stream)) return rc; }
     else wgrad_kernel<8, 8, false><<<grid, 512, 0, stream>>>(job(kDyFeat, 256, kActH + 7 * 256, 256, 0, 0));
     reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {0, 0}}, 8);
     // views_linears.0: dYv x cat([feature, dir encoding]) (network.py:63)
-    if (x3) { if (const int rc = launch_wgrad_x3p<4, 9>(job(kDyV, 128, kActFeat, 256, kActDpe, 32), slices, stream)) return rc; }
+    if (h2) { if (const int rc = launch_wgrad_h2p<4, 9>(job(kDyV, 128, kActFeat, 256, kActDpe, 32, kGmaxViews), slices, stream)) return rc; }
+    else if (x3) { if (const int rc = launch_wgrad_x3p<4, 9>(job(kDyV, 128, kActFeat, 256, kActDpe, 32), slices, stream)) return rc; }
     else wgrad_kernel<4, 9, false><<<grid, 256, 0, stream>>>(job(kDyV, 128, kActFeat, 256, kActDpe, 32));
     reduce(128, 288, 128, ColMap{{256, 32}, {0, 4}, {0, 256}}, 10);
     // alpha_linear: d sigma (raw row 3) x h7;  rgb_linear: d rgb (raw rows 0..2) x hv

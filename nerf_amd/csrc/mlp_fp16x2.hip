@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
                                                               const char* __restrict__ packed_t,  // two-term W^T stream
                                                               const float4* __restrict__ graw, const unsigned* __restrict__ masks,
                                                               int64_t n_points, int64_t n_groups, float* __restrict__ dys,
-                                                              const unsigned* __restrict__ gmax_bits) {
+                                                              unsigned* gmax_bits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -501,16 +501,9 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
         float4* dst = reinterpret_cast<float4*>(smem + kHLdsConstOff);
         for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
     }
-    // loss scale 2^S with 2^S * max |d raw| in [16, 32): S = 4 - exponent(max); max = 0, subnormal or not finite: S = 0
-    float scale = 1.f, unscale = 1.f;
-    {
-        const int e = int((*gmax_bits >> 23) & 0xffu);
-        if (e > 0 && e < 255) {
-            int S = 4 - (e - 127);
-            S = S > 100 ? 100 : S < -100 ? -100 : S;
-            scale = __uint_as_float(unsigned(127 + S) << 23), unscale = __uint_as_float(unsigned(127 - S) << 23);
-        }
-    }
+    // loss scale 2^S with 2^S * max |d raw| in [16, 32); max = 0, subnormal or not finite: S = 0
+    const int S = scale_exponent(*gmax_bits, kChainScaleTarget);
+    const float scale = exp2i(S), unscale = exp2i(-S);
     __syncthreads();
     const float* cst = reinterpret_cast<const float*>(smem + kHLdsConstOff);
     const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
@@ -555,7 +548,19 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
         op.kscale = unscale;
 #pragma unroll
         for (int w = 0; w < 4; ++w) op.m[w] = ~0u;
+        // op.ovf is the largest |scaled dY| of the rows the layer just stored: the range guard's input, and -- reduced
+        // over the batch into word 1 + (row set) -- what the fp16x2 weight-gradient GEMMs scale that row set by
+        float ovf_all = 0.f;
+        auto layer_max = [&](int word) {
+            float m = op.ovf;
+            ovf_all = fmaxf(ovf_all, m);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0 && m < kF16Limit) atomicMax(gmax_bits + word, __float_as_uint(m));
+            op.ovf = 0.f;
+        };
         h2_hidden_layer<8, 0, kOpBwd, 4>(st, lane, nullptr, X, nullptr, Y, Z, YL, op);
+        layer_max(kGmaxViews);
         // li = 0: d h7 = W_feature^T . d feature (no activation between feature_linear and views_linears: all-ones mask,
         // stored as the dY rows of feature_linear); li = 1 .. 7: layer l = 8 - li, dY_l = relu'(h_l) * d h_l (+ the
         // alpha_linear term for h7), d h_{l-1} = W_l^T . dY_l.  One body, run-time loop.
@@ -566,9 +571,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
             for (int w = 0; w < 4; ++w) op.m[w] = li == 0 ? 0xffffffffu : mrow[(l * 4 + w) * 64];
             op.dsig = li == 1 ? g.w : 0.f;                       // h7 also feeds alpha_linear
             h2_hidden_layer<8, 0, kOpBwd>(st, lane, nullptr, X, nullptr, Y, Z, YL, op);
+            layer_max(li == 0 ? kGmaxFeat : kGmaxLayer0 + l);
         }
         {   // dY_0 = relu'(h_0) * d h_0 (the encoding needs no gradient: the chain ends here)
-            float ovf = op.ovf;
+            float ovf = ovf_all;
             ovf = fmaxf(ovf, __shfl_xor(ovf, 32));
             const float out_scale = ovf < kF16Limit ? unscale : __builtin_nanf("");   // a point that left the range says so
             OpBwdMask last;
@@ -577,13 +583,19 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
             for (int w = 0; w < 4; ++w) last.m[w] = mrow[w * 64];
             last.aw = aw;
             last.dsig = 0.f;
+            float m0 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                const f32x16 x = mask16(Y[i], (last.m[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+#pragma unroll
+                for (int t = 0; t < 16; t += 2) track_max(m0, x[t], x[t + 1]);
                 f32x16 y = Y[i];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) y[t] *= out_scale;
                 (void)last(i, y);
             }
+            op.ovf = m0;
+            layer_max(kGmaxLayer0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
@@ -634,7 +646,7 @@ int launch_dgrad_h2(const float* packed, const void* packed_t, const float* grad
             return NRF_ERR_LAUNCH;
         attr_set[dev] = true;
     }
-    if (hipMemsetAsync(gmax, 0, 4, stream) != hipSuccess) return NRF_ERR_RUNTIME;
+    if (hipMemsetAsync(gmax, 0, 256, stream) != hipSuccess) return NRF_ERR_RUNTIME;
     grad_max_kernel<<<dim3(unsigned(cus)), 256, 0, stream>>>(reinterpret_cast<const float4*>(grad_raw), n_points, gmax);
     mlp_dgrad_h2_kernel<<<dim3(unsigned(groups < cus ? groups : cus)), 256, kHLdsBytes, stream>>>(
         packed, static_cast<const char*>(packed_t), reinterpret_cast<const float4*>(grad_raw), masks, n_points, groups, dys, gmax);

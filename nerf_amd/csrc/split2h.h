@@ -69,6 +69,20 @@ __device__ __forceinline__ void split_block_f16(const f32x16& v, u32x4 (&out)[2]
     for (int t = 0; t < 16; t += 2) track_max(ovf, v[t], v[t + 1]);
     split_block_f16(v, out);
 }
+// The backward's power-of-two loss scale (mlp_fp16x2.hip: mlp_dgrad_h2_kernel; mlp_bwd.hip: wgrad_h2p_kernel): S with
+// 2^S * max in [2^target, 2^(target+1)) from the bits of a non-negative float maximum; 0 for max = 0, subnormal or not
+// finite.  Both kernels derive the chain's scale from the same word with the same formula.
+__device__ __forceinline__ int scale_exponent(unsigned max_bits, int target) {
+    const int e = int((max_bits >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 0;
+    const int S = target - (e - 127);
+    return S > 100 ? 100 : S < -100 ? -100 : S;
+}
+__device__ __forceinline__ float exp2i(int S) { return __uint_as_float(unsigned(127 + S) << 23); }   // |S| <= 126
+// words of the chain's scale block (256 B of workspace, zeroed per call): max |d raw|, then max |scaled dY| per row set
+constexpr int kGmaxLayer0 = 1, kGmaxFeat = 9, kGmaxViews = 10;   // dY_l at 1 + l (l = 0 .. 7)
+constexpr int kChainScaleTarget = 4;    // the data-gradient chain: max |d raw| -> [16, 32)
+constexpr int kWgradScaleTarget = 11;   // a weight-gradient GEMM's dY operand: its row set's max -> [2048, 4096)
 }  // namespace
 
 #define NRF_MFMA_F16(a, b, c) \
