@@ -161,8 +161,8 @@ int nrf_mlp_backward_bf16x3(const float* packed, const void* packed_t_x3, const 
                             const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace, int64_t workspace_bytes,
                             float* grad_flat, nrf_stream_t stream);
 
-/* nrf_mlp_backward with the data-gradient chain on the two-term fp16 kernel (the weight-gradient GEMMs are the bf16x3
- * ones).  Gradients are far below fp16's normal range, so the chain runs at a power-of-two loss scale chosen on the
+/* nrf_mlp_backward with the data-gradient chain and the wide weight-gradient GEMMs on the two-term fp16 kernels (the
+ * GEMMs scale their dY operand per row set from maxima the chain leaves in the workspace).  Gradients are far below fp16's normal range, so the chain runs at a power-of-two loss scale chosen on the
  * device from max |grad_raw| of the call and every dY row is unscaled (exactly) before it is stored: callers see
  * ordinary fp32 gradients.  packed: nrf_pack_weights (head rows); packed_t_h2: nrf_pack_weights_transposed_fp16x2
  * (nrf_packed_bwd_fp16x2_bytes() bytes).  Same workspace, acts / masks and gradient layout as nrf_mlp_backward. */
