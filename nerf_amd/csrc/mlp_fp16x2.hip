@@ -7,10 +7,11 @@
 // loses: the measured distance from a float64 evaluation stays at the fp32 reference's own (oracle restatement:
 // oracle/nerf_oracle.py:mlp_forward(split2_f16=True); tests/test_gpu_fp16x2.py holds the fp32 kernel's bars).  Three
 // MFMAs per fp32 product instead of mlp_bf16x3.hip's six (or eight fp32 MFMAs at 1/16 of the rate).  Range: operands
-// must lie inside fp16's (|a| < 65520: a trained NeRF's activations are O(10)); beyond it the output is non-finite,
-// and the kernel says so: a point whose activations (or a network whose weights)
-// leave the range comes out as NaN, never as a finite wrong number.  Same reference path as mlp_fp32.hip (volume_renderer.py:227-231, 393-423, network.py:49-74,
-// 171-195, encoding/freq.py:31-32).
+// must lie inside fp16's (|a| < 65520: a trained NeRF's activations are O(10)), and the kernel says so when they do
+// not: a point whose activations (or a network whose weights) leave the range comes out as NaN, never as a finite wrong
+// number.  The backward chain (mlp_dgrad_h2_kernel below) runs the same machinery at a power-of-two loss scale.
+// Same reference path as mlp_fp32.hip (volume_renderer.py:227-231, 393-423, network.py:49-74, 171-195,
+// encoding/freq.py:31-32).
 //
 // Shape: mlp_bf16x3.hip's chain -- one wave = 32 points x 256 features, all 8 accumulator blocks Y of a layer live, the
 // next layer's input X made from Y just in time under the first two output blocks -- with X held as two fp16
