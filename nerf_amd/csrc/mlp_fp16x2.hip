@@ -371,27 +371,66 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
     HRing st;
     hr_start(st, packed, smem, wave, lane);
 
+    // A tile's per-lane inputs (rays: its sample depth; flat points: position and direction) are loaded ONE TILE AHEAD by
+    // loads the compiler does not see (tile_load).  A load it does see is waited for with a vmcnt that knows nothing of
+    // the ring's LDS-DMA pieces in flight, i.e. by draining the ring at the top of every tile.  These are 580 VMEM
+    // instructions old when they are used, and the counted wait at the end of a tile (<= 40 outstanding; the ring keeps
+    // at most 18) proves them complete.
+    struct TileIn { float v[7]; };   // rays: origin, direction, depth; flat points: position, direction
+    auto tile_load = [&](int64_t tg_) {
+        TileIn in;
+        in.v[6] = 0.f;
+        const int64_t tile_ = tg_ * 4 + wave;
+        int64_t p_ = tile_ * 32 + j;
+        const bool ok = p_ < n_points;
+        if (!ok) p_ = n_points - 1;
+        auto ld = [](const float* q) {
+            float r;
+            asm volatile("global_load_dword %0, %1, off" : "=a"(r) : "v"(q) : "memory");   // into an accumulation register: nothing touches it before the next tile reads it
+            return r;
+        };
+        if (rays_mode) {
+            const int64_t tile_c = p_ / 32;
+            const int64_t ray = tile_c / tiles_per_ray;
+            const int s0 = int(tile_c - ray * tiles_per_ray) * 32;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) in.v[k] = ld(a0 + ray * 3 + k), in.v[3 + k] = ld(a1 + ray * 3 + k);
+            in.v[6] = ld(zbuf + ray * z_stride + s0 + (ok ? j : int(p_ & 31)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) in.v[k] = ld(a0 + p_ * 3 + k), in.v[3 + k] = ld(a1 + p_ * 3 + k);
+        }
+        return in;
+    };
+    // the waits carry the loaded registers as operands: what reads them afterwards cannot be scheduled ahead of the wait
+#define NRF_TILE_WAIT(N, in)                                                                                             \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
+                 : "+a"(in.v[0]), "+a"(in.v[1]), "+a"(in.v[2]), "+a"(in.v[3]), "+a"(in.v[4]), "+a"(in.v[5]), "+a"(in.v[6]) \
+                 :                                                                                                       \
+                 : "memory")
+    TileIn nxt = tile_load(blockIdx.x < n_groups ? int64_t(blockIdx.x) : 0);
+    NRF_TILE_WAIT(0, nxt);
+
     for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
         const int64_t tile = tg * 4 + wave;
         int64_t pidx = tile * 32 + j;
         const bool valid = pidx < n_points;
         if (!valid) pidx = n_points - 1;
+        const TileIn cur = nxt;
+        if (tg + gridDim.x < n_groups) nxt = tile_load(tg + gridDim.x);
         float px, py, pz, dx, dy, dz;
         if (rays_mode) {
-            const int64_t tile_c = pidx / 32;
-            const int64_t ray = tile_c / tiles_per_ray;
-            const int s0 = int(tile_c - ray * tiles_per_ray) * 32;
-            const float ox = a0[ray * 3 + 0], oy = a0[ray * 3 + 1], oz = a0[ray * 3 + 2];
-            dx = a1[ray * 3 + 0], dy = a1[ray * 3 + 1], dz = a1[ray * 3 + 2];
+            const float ox = cur.v[0], oy = cur.v[1], oz = cur.v[2];
+            dx = cur.v[3], dy = cur.v[4], dz = cur.v[5];
             const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // volume_renderer.py:230 (torch's 3-element norm)
             dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
-            const float zz = zbuf[ray * z_stride + s0 + (valid ? j : int(pidx & 31))];
+            const float zz = cur.v[6];
             px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
             py = __fadd_rn(oy, __fmul_rn(zz, dy));
             pz = __fadd_rn(oz, __fmul_rn(zz, dz));
         } else {
-            px = a0[pidx * 3 + 0], py = a0[pidx * 3 + 1], pz = a0[pidx * 3 + 2];
-            dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
+            px = cur.v[0], py = cur.v[1], pz = cur.v[2];
+            dx = cur.v[3], dy = cur.v[4], dz = cur.v[5];
         }
         u32x4 pe[2][2][2], dpe[1][2][2];
         float* arow = nullptr;     // this lane's column of the tile's saved rows (mlp_fp32.hip)
@@ -466,7 +505,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
             if (!(ovf < kF16Limit)) o = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
             raw[pidx] = o;
         }
+        NRF_TILE_WAIT(40, nxt);   // the next tile's inputs (issued ~580 VMEM instructions ago) are in
     }
+#undef NRF_TILE_WAIT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
 
