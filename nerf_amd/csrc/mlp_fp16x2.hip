@@ -554,14 +554,70 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
     HRing st;
     hr_start(st, packed_t, smem, wave, lane, kXBwdChunks);
 
+    // d raw and the relu sign words are loaded one stage ahead by loads the compiler does not see (into accumulation
+    // registers; mlp_fp16x2_kernel: tile_load): loaded in place they cost a ring drain at the top of the tile and one per
+    // layer.  Stages of a tile: views (d raw + words 32, 33), layers 7 .. 1 (4 words each), layer 0 (4 words); every
+    // stage issues well over 40 vector-memory instructions, which is what the counted waits rely on.
+    float pg[4];
+    unsigned pm[4];
+    const int64_t last_tile = (n_points - 1) / 32;
+    const unsigned lane4 = unsigned(lane) * 4u;
+    auto clamp_tile = [&](int64_t tile_) { return tile_ > last_tile ? last_tile : tile_; };   // a wave past the last tile
+    auto mask_base = [&](int64_t tile_) {   // reads the last tile's inputs; its rows are zero
+        return masks + clamp_tile(tile_) * (kMaskLayers * 4 * 64);
+    };
+    // addresses as uniform base + 32-bit lane offset + immediate: one address register for the loads of a stage; the
+    // destination is an in-out operand, so a load lands in the register its wait and its reader name (as a plain
+    // output the compiler gave it a new register and copied that, unwaited, into the loop-carried one)
+#define NRF_BWD_LOAD(dst, voff, base, imm) \
+    asm volatile("global_load_dword %0, %1, %2 offset:" #imm : "+a"(dst) : "v"(voff), "s"(base) : "memory")
+    auto issue_words4 = [&](const unsigned* p) {
+        NRF_BWD_LOAD(pm[0], lane4, p, 0);
+        NRF_BWD_LOAD(pm[1], lane4, p, 256);
+        NRF_BWD_LOAD(pm[2], lane4, p, 512);
+        NRF_BWD_LOAD(pm[3], lane4, p, 768);
+    };
+    auto issue_tile = [&](int64_t tg_) {
+        const int64_t tile_ = clamp_tile(tg_ * 4 + wave);
+        const int64_t rows = n_points - tile_ * 32;   // >= 1
+        const unsigned goff = unsigned(int64_t(j) < rows ? j : int(rows) - 1) * 16u;
+        const float4* gp = graw + tile_ * 32;
+        NRF_BWD_LOAD(pg[0], goff, gp, 0);
+        NRF_BWD_LOAD(pg[1], goff, gp, 4);
+        NRF_BWD_LOAD(pg[2], goff, gp, 8);
+        NRF_BWD_LOAD(pg[3], goff, gp, 12);
+        const unsigned* p = mask_base(tile_) + 8 * 4 * 64;
+        NRF_BWD_LOAD(pm[0], lane4, p, 0);
+        NRF_BWD_LOAD(pm[1], lane4, p, 256);
+    };
+    // the waits carry the loaded registers as operands: their readers stay behind them
+#define NRF_BWD_WAIT(N)                                                                                              \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                           \
+                 : "+a"(pg[0]), "+a"(pg[1]), "+a"(pg[2]), "+a"(pg[3]), "+a"(pm[0]), "+a"(pm[1]), "+a"(pm[2]), "+a"(pm[3]) \
+                 :                                                                                                   \
+                 : "memory")
+    // a stage's values are taken out by a statement that stays ahead of the next stage's loads (volatile asm keeps its
+    // order): the old value is dead when the load's in-out operand is set up, so no copy of it -- and no copy back of
+    // the unwaited new one -- is needed.  tests/test_asm_lint.py checks the built code for exactly that.
+#define NRF_BWD_TAKE(T, src)                                                          \
+    [&] {                                                                             \
+        T r_;                                                                         \
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r_) : "a"(src));              \
+        return r_;                                                                    \
+    }()
+    pg[0] = pg[1] = pg[2] = pg[3] = 0.f, pm[0] = pm[1] = pm[2] = pm[3] = 0u;
+    issue_tile(blockIdx.x < n_groups ? int64_t(blockIdx.x) : 0);
+    NRF_BWD_WAIT(0);
+
     for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
         const int64_t tile = tg * 4 + wave;
-        int64_t pidx = tile * 32 + j;
-        const bool valid = pidx < n_points;
-        if (!valid) pidx = n_points - 1;
-        float4 g = graw[pidx];
+        const bool valid = tile * 32 + j < n_points;
+        float4 g = make_float4(NRF_BWD_TAKE(float, pg[0]), NRF_BWD_TAKE(float, pg[1]), NRF_BWD_TAKE(float, pg[2]),
+                               NRF_BWD_TAKE(float, pg[3]));
         if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
-        const unsigned* mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+        const unsigned mv0 = NRF_BWD_TAKE(unsigned, pm[0]), mv1 = NRF_BWD_TAKE(unsigned, pm[1]);
+        const unsigned* mrow = mask_base(tile);
+        issue_words4(mrow + 7 * 4 * 64);   // layer 7's words, for li = 1
         float* drow = dys + tile * (int64_t(kDyRows) * 32) + 4 * h * 32 + j;
         if (h == 0) {  // d(raw) as 4 rows for the head wgrad jobs (unscaled)
             float* r = dys + tile * (int64_t(kDyRows) * 32) + kDyRaw * 32 + j;
@@ -572,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
         f32x16 Y[8], Z[kHLead - 1], YL[kHLead];
         // rgb_linear^T on the VALU (fp32): dYv = relu'(hv) * (W_rgb^T . d rgb), stored, and the input of views^T
         {
-            const unsigned m0 = mrow[(8 * 4 + 0) * 64], m1 = mrow[(8 * 4 + 1) * 64];
+            const unsigned m0 = mv0, m1 = mv1;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 const f32x16 w0 = *reinterpret_cast<const f32x16*>(rw + kb * 32);
@@ -610,7 +666,13 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
             const int l = 8 - li;
             op.save = drow + (li == 0 ? kDyFeat : l * 256) * 32;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) op.m[w] = li == 0 ? 0xffffffffu : mrow[(l * 4 + w) * 64];
+            for (int w = 0; w < 4; ++w) op.m[w] = 0xffffffffu;
+            if (li > 0) {
+                NRF_BWD_WAIT(40);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) op.m[w] = NRF_BWD_TAKE(unsigned, pm[w]);
+                issue_words4(mrow + (l - 1) * 4 * 64);   // the next stage's words
+            }
             op.dsig = li == 1 ? g.w : 0.f;                       // h7 also feeds alpha_linear
             h2_hidden_layer<8, 0, kOpBwd>(st, lane, nullptr, X, nullptr, Y, Z, YL, op);
             layer_max(li == 0 ? kGmaxFeat : kGmaxLayer0 + l);
@@ -621,8 +683,10 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
             const float out_scale = ovf < kF16Limit ? unscale : __builtin_nanf("");   // a point that left the range says so
             OpBwdMask last;
             last.dst = drow;
+            NRF_BWD_WAIT(40);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) last.m[w] = mrow[w * 64];
+            for (int w = 0; w < 4; ++w) last.m[w] = NRF_BWD_TAKE(unsigned, pm[w]);
+            if (tg + gridDim.x < n_groups) issue_tile(tg + gridDim.x);
             last.aw = aw;
             last.dsig = 0.f;
             float m0 = 0.f;
@@ -639,7 +703,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_h2_kernel(const float* __res
             op.ovf = m0;
             layer_max(kGmaxLayer0);
         }
+        NRF_BWD_WAIT(40);   // the next tile's inputs, 128 stores old, are in
     }
+#undef NRF_BWD_WAIT
+#undef NRF_BWD_LOAD
+#undef NRF_BWD_TAKE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
 
