@@ -378,6 +378,7 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_x3_kernel(WgradJob job) {
 // 16 h + 4 (tid & 3) ..): the registers of half h are refilled from the tile after next as soon as they have been
 // split, one half-step before they are needed again.  One barrier per half.
 constexpr int kX3HalfRow = 48;
+constexpr int kWgradDepth = 3;   // wgrad_h2p_kernel: register sets of loaded halves (2: 4 % slower; 4: spills, 2.5 % slower)
 
 // one third of split_pair (split3.h), so that a pair's 15 instructions spread over three MFMA gaps
 __device__ __forceinline__ void split_phase(float a, float b, int phase, unsigned& p0, unsigned& p1, unsigned& p2, float& r0,
@@ -587,7 +588,8 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
     constexpr int NBh = (K * 4 + NT - 1) / NT;      // ... of X
     static_assert(M * 4 % NT == 0 && NAh >= 1, "whole dY pieces per thread");
     constexpr int NI = NAh + NBh;                   // items per half
-    float4 reg[2][NI];                              // [half][item]: dY items first
+    constexpr int D = kWgradDepth;                  // register sets: a half is loaded D - 1 half-steps before its split
+    float4 reg[D][NI];                              // [half mod D][item]: dY items first
     float bsum[NAh];   // lanes with q == 0: row sum of dY row r0row + (NT / 4) * j
 #pragma unroll
     for (int n = 0; n < NAh; ++n) bsum[n] = 0.f;
@@ -686,19 +688,33 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
     if (n_half > 0) {
         char* st0 = s_x3;
         char* st1 = s_x3 + kStage;
-        load_half(0, reg[0]);
-        load_half(1, reg[1]);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < n_half) load_half(d, reg[d]);
 #pragma unroll
         for (int w = 0; w < W; ++w) split_sub(st0, reg[0], w);   // the first half: nothing to hide it under
         __syncthreads();
-        for (int64_t hs = 0; hs < n_half; hs += 2) {
-            if (hs + 2 < n_half) load_half(hs + 2, reg[0]);
-            half_step(st0, st1, reg[1], true);
-            __syncthreads();
-            const bool more = hs + 2 < n_half;
-            if (hs + 3 < n_half) load_half(hs + 3, reg[1]);
-            half_step(st1, st0, reg[0], more);
-            __syncthreads();
+        // half-step hs: MFMAs on stage hs & 1, the split of half hs + 1 (set (hs + 1) % D) into the other stage; set
+        // hs % D was split one half-step ago and is refilled with half hs + D.  (n_half is even.)
+        constexpr int U = D % 2 ? 2 * D : D;   // unrolled so that set (hs % D) and stage (hs & 1) are compile-time
+        for (int64_t hs = 0; hs < n_half; hs += U) {
+#pragma unroll
+            for (int d = 0; d < U; ++d) {
+                if (hs + d < n_half) {
+#ifndef WG_ABL_NOLOAD   // (timing-only ablations, tools/debug/wg_ab.sh: wrong results)
+                    // (asking for both halves of a tile together, whole 128-byte rows per burst, measured 5 % slower)
+                    if (hs + d + D < n_half) load_half(hs + d + D, reg[d % D]);
+#endif
+#ifdef WG_ABL_NOSPLIT
+                    half_step(d & 1 ? st1 : st0, d & 1 ? st0 : st1, reg[(d + 1) % D], false);
+#else
+                    half_step(d & 1 ? st1 : st0, d & 1 ? st0 : st1, reg[(d + 1) % D], hs + d + 1 < n_half);
+#endif
+#ifndef WG_ABL_NOBAR
+                    __syncthreads();
+#endif
+                }
+            }
         }
     }
     float* out = job.partial + int64_t(slice) * M * K;
