@@ -701,7 +701,7 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
 #pragma unroll
             for (int d = 0; d < U; ++d) {
                 if (hs + d < n_half) {
-#ifndef WG_ABL_NOLOAD   // (timing-only ablations, tools/debug/wg_ab.sh: wrong results)
+#ifndef WG_ABL_NOLOAD   // (timing-only ablations, tools/debug/lib_ab.sh: wrong results)
                     // (asking for both halves of a tile together, whole 128-byte rows per burst, measured 5 % slower)
                     if (hs + d + D < n_half) load_half(hs + d + D, reg[d % D]);
 #endif

@@ -108,6 +108,9 @@ struct OpInBase {
     template <int MODE, bool SCALED = false>
     __device__ __forceinline__ void keep(int blk, int q, float a, float b) {
         if (MODE == kOpFwd) return;
+#ifdef NRF_ABL_NOKEEP   // timing only (tools/debug/lib_ab.sh)
+        return;
+#endif
         const int t0 = 2 * q, t1 = 2 * q + 1;
         save[(32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32] = SCALED ? a * kscale : a;
         save[(32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32] = SCALED ? b * kscale : b;
