@@ -50,7 +50,11 @@ static_assert(kHPieces * (kHRing - 2) + kHLook < 64, "vmcnt is a 6-bit counter")
 __device__ __forceinline__ void split_tile_h(const f32x16& v, u32x4 (&out)[2][2]) { split_block_f16(v, out); }
 
 // ---- weight packing ------------------------------------------------------------------------
-__global__ void hpack_layer_kernel(XPackLayer p, unsigned* status) {   // one thread writes the two terms of one weight
+// all layers of a stream in one launch (blockIdx.y = layer; mlp_fp32.hip: pack_layers_kernel)
+constexpr int kHPackBatch = 11;
+struct HPackBatch { XPackLayer l[kHPackBatch]; };
+__global__ void hpack_layers_kernel(HPackBatch b, unsigned* status) {   // one thread writes the two terms of one weight
+    const XPackLayer& p = b.l[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= xpack_total(p)) return;
     int step, lane, jj;
@@ -776,15 +780,18 @@ NRF_EXPORT int nrf_pack_weights_transposed_fp16x2(const float* const* w, void* p
     unsigned short* base = static_cast<unsigned short*>(packed_t);
     nrf_launch_begin();
     int step = 0;
+    HPackBatch batch;
+    int n_batch = 0, max_total = 0;
     auto launch = [&](const float* W, int ldw, int in_blocks, int col0) {   // in_blocks = k-blocks = rows of W / 32
-        XPackLayer p{W, base + int64_t(step) * (kHStepBytes / 2), ldw, 8, 0, in_blocks, 0, 0, 0, 0, col0, 0, kHLead, 1};
+        batch.l[n_batch++] = XPackLayer{W, base + int64_t(step) * (kHStepBytes / 2), ldw, 8, 0, in_blocks, 0, 0, 0, 0, col0, 0, kHLead, 1};
         const int total = 8 * in_blocks * 2 * 512;
-        hpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p, nullptr);
+        max_total = total > max_total ? total : max_total;
         step += 8 * in_blocks * 2;
     };
     launch(w[10], 283, 4, 0);   // views^T: 128 outputs of views_linears.0 contracted, 256 feature columns out
     launch(w[8], 256, 8, 0);    // feature^T
     for (int l = 7; l >= 1; --l) launch(w[l], l == 5 ? 319 : 256, 8, l == 5 ? 63 : 0);
+    hpack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch, nullptr);
     return nrf_launch_status();
 }
 
@@ -800,12 +807,16 @@ NRF_EXPORT int nrf_pack_weights_fp16x2(const float* const* w, const float* const
     unsigned* status = reinterpret_cast<unsigned*>(static_cast<char*>(packed) + kHStatusOff);
     if (hipMemsetAsync(status, 0, 16, stream) != hipSuccess) return NRF_ERR_RUNTIME;
     nrf_launch_begin();
+    HPackBatch batch;
+    int n_batch = 0, max_total = 0;
     auto launch = [&](XPackLayer p, int step0) {
         p.dst = base + int64_t(step0) * (kHStepBytes / 2);
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
-        hpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p, status);
+        batch.l[n_batch++] = p;
+        max_total = total > max_total ? total : max_total;
     };
     xpack_forward_layers(w, launch, kHLead);
+    hpack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch, status);
     const PackSmall s = xpack_small(w, b, packed, kHSmallFloatOff);
     pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
     return nrf_launch_status();

@@ -37,7 +37,12 @@ struct PackLayer {
     int transpose;                      // hidden part only: stream W^T (rows = input features) for the dgrad chain
 };
 
-__global__ void pack_layer_kernel(PackLayer p) {
+// all layers of a stream in one launch (blockIdx.y = layer; a training step re-packs four streams after every update,
+// and eleven 4-us launches per stream were a third of a millisecond per step)
+constexpr int kPackBatch = 11;
+struct PackBatch { PackLayer l[kPackBatch]; };
+__global__ void pack_layers_kernel(PackBatch b) {
+    const PackLayer& p = b.l[blockIdx.y];
     const int nkb = p.pre_kb + p.hid_kb + p.post_kb;
     const int total = p.nob * nkb * 4 * kStepFloats;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -71,10 +76,16 @@ NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, fl
     if (!nrf_aligned16(packed)) return NRF_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     nrf_launch_begin();
+    PackBatch batch;
+    int n_batch = 0, max_total = 0;
+    auto add = [&](const PackLayer& p) {
+        batch.l[n_batch++] = p;
+        const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 4 * kStepFloats;
+        max_total = total > max_total ? total : max_total;
+    };
     auto launch = [&](PackLayer p, int layer_slot) {
         p.dst = packed + int64_t(kLayerStep[layer_slot]) * kStepFloats;
-        const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 4 * kStepFloats;
-        pack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+        add(p);
     };
     // pts_linears.0: 63 PE -> 256
     launch(PackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0}, 0);
@@ -84,13 +95,14 @@ NRF_EXPORT int nrf_pack_weights(const float* const* w, const float* const* b, fl
             // a plain 256->256 layer (so it shares the hidden-layer code) followed by a PE pass that accumulates.
             launch(PackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0}, 5);
             PackLayer pe_part{w[5], packed + int64_t(kLayerStep[5] + kStepsHidden) * kStepFloats, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0};
-            pack_layer_kernel<<<(kStepsL0 * kStepFloats + 255) / 256, 256, 0, stream>>>(pe_part);
+            add(pe_part);
         } else
             launch(PackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, l);
     }
     launch(PackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, 8);  // feature_linear
     // views_linears.0: network.py:63 cat([feature, input_views]): 256 hidden then 27 dir PE -> 128
     launch(PackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256}, 9);
+    pack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch);
     PackSmall s;
     for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
     s.bias[8] = b[8];
@@ -117,16 +129,20 @@ NRF_EXPORT int nrf_pack_weights_transposed(const float* const* w, float* packed_
     if (!nrf_aligned16(packed_t)) return NRF_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     nrf_launch_begin();
+    PackBatch batch;
+    int n_batch = 0, max_total = 0;
     int step = 0;
     auto launch = [&](const float* W, int ldw, int in_blocks, int out_blocks, int col0) {
-        PackLayer p{W, packed_t + int64_t(step) * kStepFloats, ldw, in_blocks, 0, out_blocks, 0, 0, 0, 0, col0, 0, 1};
+        const PackLayer p{W, packed_t + int64_t(step) * kStepFloats, ldw, in_blocks, 0, out_blocks, 0, 0, 0, 0, col0, 0, 1};
         const int total = in_blocks * out_blocks * 4 * kStepFloats;
-        pack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+        batch.l[n_batch++] = p;
+        max_total = total > max_total ? total : max_total;
         step += in_blocks * out_blocks * 4;
     };
     launch(w[10], 283, 8, 4, 0);  // views^T: 256 inputs x 128 outputs
     launch(w[8], 256, 8, 8, 0);   // feature^T
     for (int l = 7; l >= 1; --l) launch(w[l], l == 5 ? 319 : 256, 8, 8, l == 5 ? 63 : 0);
+    pack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch);
     (void)hipMemsetAsync(packed_t + int64_t(kBwdSteps) * kStepFloats, 0, size_t(kPrefetch) * kStepFloats * 4, stream);
     return nrf_launch_status();
 }
