@@ -924,9 +924,16 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 0);
     for (int l = 1; l <= 7; ++l) {
         if (l == 5) {  // cat([encoding, h4]) (network.py:58)
-            // (320 columns: wgrad_h2p<8, 10> needs 96 B of scratch per lane and measured 3 % slower than the bf16x3 kernel,
-            // which reads the same unscaled fp32 rows)
-            if (x3 || h2) { if (const int rc = launch_wgrad_x3<8, 10>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256), slices, stream)) return rc; }
+            if (h2) {
+                // 320 columns as the 256 hidden ones + the 64 of the encoding, two GEMMs over the same dY rows (480 against
+                // 570 us for the one-pass bf16x3 kernel; wgrad_h2p<8, 10> itself needs 96 B of scratch per lane and was slower still)
+                if (const int rc = launch_wgrad_h2p<8, 8>(job(5 * 256, 256, kActH + 4 * 256, 256, 0, 0, kGmaxLayer0 + 5), slices, stream)) return rc;
+                reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {63, 0}}, 5);
+                if (const int rc = launch_wgrad_h2p<8, 2>(job(5 * 256, 256, kActPe, 64, 0, 0, kGmaxLayer0 + 5), slices, stream)) return rc;
+                reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 5);
+                continue;
+            }
+            if (x3) { if (const int rc = launch_wgrad_x3<8, 10>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256), slices, stream)) return rc; }
             else wgrad_kernel<8, 10, false><<<grid, 512, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
             reduce(256, 320, 256, ColMap{{64, 256}, {10, 0}, {0, 63}}, 5);
         } else {
