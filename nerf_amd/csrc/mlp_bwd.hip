@@ -781,6 +781,58 @@ __device__ __forceinline__ int map_col(const ColMap& cm, int c) {
     return col < 0 ? -1 : cm.seg_col0[seg] + col;
 }
 
+// alpha_linear / rgb_linear weight gradients: dW[a][k] = sum_p dA[a][p] * X[k][p] with NA <= 3 rows of d raw -- a job for
+// HBM (X is read once, K * 128 B per tile) and the VALU, not for a 32-row MFMA tile with one or three live rows
+// (wgrad_kernel<4, *, true>: 2.1x the time).  A thread owns one float4 (4 points) of row r of each 32-row pass; the
+// eight threads of a row are summed at the end.  partial: [slice][NA][K], pbias: [slice][NA]; fp32 throughout.
+template <int NA, int K>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(WgradJob job) {
+    constexpr int P = K / 32;
+    const int tid = threadIdx.x, q = tid & 7, r = tid >> 3;
+    const int slice = blockIdx.x;
+    const int64_t t0 = int64_t(slice) * job.tiles_per_slice;
+    int64_t t1 = t0 + job.tiles_per_slice;
+    if (t1 > job.n_tiles) t1 = job.n_tiles;
+    float acc[P][NA], bsum[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        bsum[a] = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p][a] = 0.f;
+    }
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        const float* pa = job.a + (tile * job.a_stride + job.a_row0) * 32 + q * 4;
+        const float* xb = job.x + (tile * job.x_stride + job.x_row0[0] + r) * 32 + q * 4;
+        float4 da[NA], xv[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) xv[p] = *reinterpret_cast<const float4*>(xb + p * 32 * 32);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) da[a] = *reinterpret_cast<const float4*>(pa + a * 32);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            bsum[a] += (da[a].x + da[a].y) + (da[a].z + da[a].w);
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                acc[p][a] = fmaf(xv[p].w, da[a].w, fmaf(xv[p].z, da[a].z, fmaf(xv[p].y, da[a].y, fmaf(xv[p].x, da[a].x, acc[p][a]))));
+        }
+    }
+    auto sum8 = [](float v) {   // over the eight consecutive lanes of a row
+        v += __shfl_xor(v, 1), v += __shfl_xor(v, 2), v += __shfl_xor(v, 4);
+        return v;
+    };
+    float* out = job.partial + int64_t(slice) * NA * K;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const float v = sum8(acc[p][a]);
+            if (q == 0) out[a * K + p * 32 + r] = v;
+        }
+        const float b = sum8(bsum[a]);
+        if (tid == 0) job.pbias[int64_t(slice) * NA + a] = b;
+    }
+}
+
 // Sum of the split-P partials, scattered into the reference's (out, in) layout.  A block is 256 columns x kRedY
 // slice groups: the 256 slices of one element are summed by kRedY threads (16 independent loads in flight each) and
 // combined through LDS -- with one thread per element the 12 reduces of a backward pass ran at 52 GB/s.
@@ -954,10 +1006,26 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
     else wgrad_kernel<4, 9, false><<<grid, 256, 0, stream>>>(job(kDyV, 128, kActFeat, 256, kActDpe, 32));
     reduce(128, 288, 128, ColMap{{256, 32}, {0, 4}, {0, 256}}, 10);
     // alpha_linear: d sigma (raw row 3) x h7;  rgb_linear: d rgb (raw rows 0..2) x hv
-    wgrad_kernel<4, 2, true><<<grid, 256, 0, stream>>>(job(kDyRaw + 3, 1, kActH + 7 * 256, 256, 0, 0));
-    reduce(32, 256, 1, ColMap{{256, 0}, {0, 0}, {0, 0}}, 9);
-    wgrad_kernel<4, 1, true><<<grid, 256, 0, stream>>>(job(kDyRaw, 3, kActHv, 128, 0, 0));
-    reduce(32, 128, 3, ColMap{{128, 0}, {0, 0}, {0, 0}}, 11);
+    // (four times the slices of the wide GEMMs: a workgroup is 256 threads with 32 KB of loads in flight, several fit a CU;
+    // [slices][3][256] floats fit the partial buffer many times over)
+    {
+        const int head_slices = int(n_tiles < 1024 ? n_tiles : 1024);
+        const int head_tps = int((n_tiles + head_slices - 1) / head_slices);
+        auto head_job = [&](int a_row0, int a_rows, int xr0, int xn0) {
+            WgradJob j = job(a_row0, a_rows, xr0, xn0, 0, 0);
+            j.tiles_per_slice = head_tps;
+            return j;
+        };
+        auto head_reduce = [&](int M, int K, int layer) {
+            wgrad_reduce_kernel<<<(M * K + kRedX - 1) / kRedX, dim3(kRedX, kRedY), 0, stream>>>(
+                partial, pbias, head_slices, M, K, M, ColMap{{K, 0}, {0, 0}, {0, 0}}, grad_flat + woff[layer], kLayerIn[layer],
+                grad_flat + boff[layer]);
+        };
+        head_wgrad_kernel<1, 256><<<dim3(head_slices), 256, 0, stream>>>(head_job(kDyRaw + 3, 1, kActH + 7 * 256, 256));
+        head_reduce(1, 256, 9);
+        head_wgrad_kernel<3, 128><<<dim3(head_slices), 256, 0, stream>>>(head_job(kDyRaw, 3, kActHv, 128));
+        head_reduce(3, 128, 11);
+    }
     return nrf_launch_status();
 }
 
