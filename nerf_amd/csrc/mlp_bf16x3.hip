@@ -138,9 +138,9 @@ struct OpIn : OpInBase {
     __device__ __forceinline__ void input(const f32x16& y, int blk, int q, float& a, float& b) {
         if (MODE == kOpBwd) {
             const float2 w = *reinterpret_cast<const float2*>(aw + blk * 32 + 2 * q);
-            const unsigned bits = m[blk >> 1] >> (16 * (blk & 1) + 2 * q);
-            a = (bits & 1u) ? fmaf(w.x, dsig, y[2 * q]) : 0.f;
-            b = (bits & 2u) ? fmaf(w.y, dsig, y[2 * q + 1]) : 0.f;
+            const int word = int(m[blk >> 1]), at = 16 * (blk & 1) + 2 * q;   // (split_stream.h: OpInBase::input)
+            a = __int_as_float(__float_as_int(fmaf(w.x, dsig, y[2 * q])) & __builtin_amdgcn_sbfe(word, at, 1));
+            b = __int_as_float(__float_as_int(fmaf(w.y, dsig, y[2 * q + 1])) & __builtin_amdgcn_sbfe(word, at + 1, 1));
         } else {
             const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
             a = __int_as_float(b0 > lim ? b0 : lim), b = __int_as_float(b1 > lim ? b1 : lim);
