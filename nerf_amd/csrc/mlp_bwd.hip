@@ -589,29 +589,63 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
     static_assert(M * 4 % NT == 0 && NAh >= 1, "whole dY pieces per thread");
     constexpr int NI = NAh + NBh;                   // items per half
     constexpr int D = kWgradDepth;                  // register sets: a half is loaded D - 1 half-steps before its split
-    float4 reg[D][NI];                              // [half mod D][item]: dY items first
+    // [half mod D][item]: dY items first.  The loads are inline asm and so are their waits: left to the compiler, every
+    // consumption of a set came out as s_waitcnt vmcnt(0) or (1) -- its counter model gives up on the predicated loads
+    // and the unrolled loop's back edge -- i.e. each half-step waited for the loads it had just issued for three
+    // half-steps later, and the kernel spent half its wave time in s_waitcnt.  In issue order the sets younger than the
+    // one about to be split hold 2 NI loads: the wait is vmcnt(2 NI), and names the set's registers so that no read of
+    // them can be scheduled ahead of it.
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v reg[D][NI];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int n = 0; n < NI; ++n) reg[d][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // in-out: the load lands in the register its wait and its readers name.  One wave per SIMD (NW = 4: 9 accumulator
+    // blocks + 21 loaded float4 do not fit 256 VGPRs): the sets live in accumulation registers -- as "v" operands the
+    // allocator parked them there itself, by copies placed between a load and its wait.
+    constexpr bool kSetsInAgprs = NW == 4;
+    auto gload = [](f32x4v& dst, const float* p) {
+        if constexpr (kSetsInAgprs) asm volatile("global_load_dwordx4 %0, %1, off" : "+a"(dst) : "v"(p) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(p) : "memory");
+    };
     float bsum[NAh];   // lanes with q == 0: row sum of dY row r0row + (NT / 4) * j
 #pragma unroll
     for (int n = 0; n < NAh; ++n) bsum[n] = 0.f;
 
-    auto load_half = [&](int64_t hs, float4 (&r)[NI]) {   // hs = half-step index inside the slice
+    // hs = half-step index inside the slice.  Past the slice's end the last half is loaded again and never used: every
+    // half-step then issues NI loads, "two sets are younger" holds from the prologue to the last half-step, and ONE
+    // wait statement serves them all (a second form for the tail sat in another branch, and the allocator bridged the
+    // two with copies of the set placed BEFORE that wait: stale data in a slice's last half-steps).
+    auto load_half = [&](int64_t hs, f32x4v (&r)[NI]) {
+        hs = hs < n_half ? hs : n_half - 1;
         const int64_t tile = t0 + (hs >> 1);
         const int h = int(hs & 1);
         const float* pa = job.a + (tile * job.a_stride + job.a_row0) * 32 + (4 * h + q) * 4;
 #pragma unroll
-        for (int j = 0; j < NAh; ++j) {
-            const int row = r0row + (NT / 4) * j;
-            r[j] = row < job.a_rows ? *reinterpret_cast<const float4*>(pa + row * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int j = 0; j < NAh; ++j) gload(r[j], pa + (r0row + (NT / 4) * j) * 32);   // all M rows are live (launcher)
         const float* xb = job.x + tile * job.x_stride * 32 + (4 * h + q) * 4;
 #pragma unroll
         for (int j = 0; j < NBh; ++j) {
-            const int row = r0row + (NT / 4) * j;
-            if (row < K) {
-                const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
-                r[NAh + j] = *reinterpret_cast<const float4*>(xb + src_row * 32);
-            }
+            int row = r0row + (NT / 4) * j;
+            row = row < K ? row : K - 1;   // a thread past the last row loads a live one and stores nothing (split_sub)
+            const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
+            gload(r[NAh + j], xb + src_row * 32);
         }
+    };
+    // the set `r` is complete once at most the two younger sets' loads are in flight
+    auto wait_set = [&](f32x4v (&r)[NI]) {
+        static_assert(NI == 3 || NI == 4 || NI == 7, "one operand list per NI");
+        static_assert(D == 3, "vmcnt((D - 1) NI)");
+        static_assert(kSetsInAgprs == (NI == 7), "the NI = 7 operand list is the accumulation-register one");
+        if constexpr (NI == 3) asm volatile("s_waitcnt vmcnt(6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) : : "memory");
+        else if constexpr (NI == 4)
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(14)"
+                         : "+a"(r[0]), "+a"(r[1]), "+a"(r[2]), "+a"(r[3]), "+a"(r[4]), "+a"(r[5]), "+a"(r[6])
+                         :
+                         : "memory");
     };
     // sub-slice w of the split of one half (items x 2 pairs x 3 phases); the item's 8-byte stores ride on its last one
     unsigned p1[3], p2[3];   // the planes' words of the item's first / second pair
@@ -631,12 +665,12 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
             else p[1] = pk_f16_scaled(r0, r1);
         }
     };
-    auto split_sub = [&](char* stage, float4 (&r)[NI], int w) {
+    auto split_sub = [&](char* stage, f32x4v (&r)[NI], int w) {
         const int item = w / 6, ph = w % 6;
         const bool is_a = item < NAh;
         const int row = r0row + (NT / 4) * (is_a ? item : item - NAh);
         if (!is_a && row >= K) return;
-        const float4 v = r[item];
+        const f32x4v v = r[item];
         if (ph < 3) pair_phase(is_a, v.x, v.y, ph, p1);
         else pair_phase(is_a, v.z, v.w, ph - 3, p2);
         if (ph == 5) {
@@ -654,11 +688,24 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
             }
         }
     };
+    auto drain_sets = [&] {   // everything asked for so far has landed
+        if constexpr (NI == 3)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(reg[0][0]), "+v"(reg[0][1]), "+v"(reg[0][2]), "+v"(reg[1][0]), "+v"(reg[1][1]),
+                         "+v"(reg[1][2]), "+v"(reg[2][0]), "+v"(reg[2][1]), "+v"(reg[2][2]) : : "memory");
+        else if constexpr (NI == 4)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(reg[0][0]), "+v"(reg[0][1]), "+v"(reg[0][2]), "+v"(reg[0][3]), "+v"(reg[1][0]),
+                         "+v"(reg[1][1]), "+v"(reg[1][2]), "+v"(reg[1][3]), "+v"(reg[2][0]), "+v"(reg[2][1]), "+v"(reg[2][2]),
+                         "+v"(reg[2][3]) : : "memory");
+        else   // (a statement takes at most 30 operands and an in-out one counts twice: set by set)
+            for (int d = 0; d < D; ++d)
+                asm volatile("s_waitcnt vmcnt(0)" : "+a"(reg[d][0]), "+a"(reg[d][1]), "+a"(reg[d][2]), "+a"(reg[d][3]), "+a"(reg[d][4]),
+                             "+a"(reg[d][5]), "+a"(reg[d][6]) : : "memory");
+    };
     constexpr int W = NI * 6;          // sub-slices per half
     constexpr int S = 3 * KB;          // MFMA gaps per half
 
     // one half-step: MFMAs on stage `cur` (KB groups of three), the split of the next half into the other stage in the gaps
-    auto half_step = [&](const char* cur, char* nxt, float4 (&rn)[NI], bool do_split) {
+    auto half_step = [&](const char* cur, char* nxt, f32x4v (&rn)[NI], bool do_split) {
         const char* pa = cur + (wave * 32 + i) * kX3HalfRow + 16 * kh;
         const char* pb = cur + 3 * kPA + i * kX3HalfRow + 16 * kh;
         auto frag_b = [&](int k, int t) { return *reinterpret_cast<const u32x4*>(pb + t * kPB + k * 32 * kX3HalfRow); };
@@ -690,33 +737,71 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
         char* st1 = s_x3 + kStage;
 #pragma unroll
         for (int d = 0; d < D; ++d)
-            if (d < n_half) load_half(d, reg[d]);
+            load_half(d, reg[d]);
+        wait_set(reg[0]);
 #pragma unroll
         for (int w = 0; w < W; ++w) split_sub(st0, reg[0], w);   // the first half: nothing to hide it under
         __syncthreads();
         // half-step hs: MFMAs on stage hs & 1, the split of half hs + 1 (set (hs + 1) % D) into the other stage; set
         // hs % D was split one half-step ago and is refilled with half hs + D.  (n_half is even.)
         constexpr int U = D % 2 ? 2 * D : D;   // unrolled so that set (hs % D) and stage (hs & 1) are compile-time
-        for (int64_t hs = 0; hs < n_half; hs += U) {
-#pragma unroll
-            for (int d = 0; d < U; ++d) {
-                if (hs + d < n_half) {
-#ifndef WG_ABL_NOLOAD   // (timing-only ablations, tools/debug/lib_ab.sh: wrong results)
-                    // (asking for both halves of a tile together, whole 128-byte rows per burst, measured 5 % slower)
-                    if (hs + d + D < n_half) load_half(hs + d + D, reg[d % D]);
+        // Half-step hs + d, d a literal: loads for half hs + d + D into set d % D, the wait for set (d + 1) % D, the
+        // MFMAs of stage d & 1 with the split of half hs + d + 1 in their gaps.  The main loop runs whole groups of U
+        // half-steps without a test inside; the remaining 0 / 2 / 4 (n_half is even) are NESTED ifs -- side by side they
+        // would give the control-flow graph paths that skip one half-step and run the next, never taken, but on them
+        // the counted wait would be wrong and tests/test_asm_lint.py cannot know that they are not.
+#ifdef WG_ABL_NOLOAD   // (timing-only ablations, tools/debug/lib_ab.sh: wrong results)
+#define NRF_WG_LOAD(d)
+#else   // (asking for both halves of a tile together, whole 128-byte rows per burst, measured 5 % slower)
+#define NRF_WG_LOAD(d) load_half(hs + (d) + D, reg[(d) % D]);
 #endif
 #ifdef WG_ABL_NOSPLIT
-                    half_step(d & 1 ? st1 : st0, d & 1 ? st0 : st1, reg[(d + 1) % D], false);
+#define NRF_WG_SPLIT(d) false
 #else
-                    half_step(d & 1 ? st1 : st0, d & 1 ? st0 : st1, reg[(d + 1) % D], hs + d + 1 < n_half);
+#define NRF_WG_SPLIT(d) hs + (d) + 1 < n_half
 #endif
-#ifndef WG_ABL_NOBAR
-                    __syncthreads();
+#ifdef WG_ABL_NOBAR
+#define NRF_WG_SYNC
+#else
+#define NRF_WG_SYNC __syncthreads();
 #endif
-                }
+#define NRF_WG_HALF(d)                                                                                  \
+    {                                                                                                   \
+        NRF_WG_LOAD(d)                                                                                  \
+        wait_set(reg[((d) + 1) % D]);                                                                   \
+        half_step((d) & 1 ? st1 : st0, (d) & 1 ? st0 : st1, reg[((d) + 1) % D], NRF_WG_SPLIT(d));       \
+        NRF_WG_SYNC                                                                                     \
+    }
+        static_assert(U == 6, "six half-steps written out below");
+        int64_t hs = 0;
+        for (; hs + U <= n_half; hs += U) {
+            NRF_WG_HALF(0) NRF_WG_HALF(1) NRF_WG_HALF(2) NRF_WG_HALF(3) NRF_WG_HALF(4) NRF_WG_HALF(5)
+        }
+        if (hs + 2 <= n_half) {
+            // the slice's last 2 or 4 half-steps: their halves hs + 1, hs + 2 are in sets 1, 2 (possibly still in flight);
+            // half hs + 3 goes into set 0 now, and ONE wait for everything, naming all three sets, ends the loading: a
+            // load past the end issued here would be dead on arrival and its registers handed out under it
+            load_half(hs + 3, reg[0]);
+            drain_sets();
+            half_step(st0, st1, reg[1], true);
+            NRF_WG_SYNC
+            half_step(st1, st0, reg[2], hs + 2 < n_half);
+            NRF_WG_SYNC
+            if (hs + 4 <= n_half) {
+                half_step(st0, st1, reg[0], true);
+                NRF_WG_SYNC
+                half_step(st1, st0, reg[0], false);
+                NRF_WG_SYNC
             }
         }
+#undef NRF_WG_HALF
+#undef NRF_WG_LOAD
+#undef NRF_WG_SPLIT
+#undef NRF_WG_SYNC
     }
+    // The loads past the slice's end are still in flight and their registers dead: nothing may be given those registers
+    // before the loads have landed (tests/test_asm_lint.py checks that nothing is).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* out = job.partial + int64_t(slice) * M * K;
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
@@ -742,6 +827,7 @@ static int launch_wgrad_h2p(const WgradJob& job, unsigned slices, hipStream_t st
             return NRF_ERR_LAUNCH;
         attr_set[dev] = true;
     }
+    if (job.a_rows != 32 * NW) return NRF_ERR_SHAPE;   // the kernel's dY loads are unconditional
     wgrad_h2p_kernel<NW, KB><<<dim3(slices), NW * 64, bytes, stream>>>(job);
     return NRF_OK;
 }
