@@ -605,14 +605,24 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
     // blocks + 21 loaded float4 do not fit 256 VGPRs): the sets live in accumulation registers -- as "v" operands the
     // allocator parked them there itself, by copies placed between a load and its wait.
     constexpr bool kSetsInAgprs = NW == 4;
-    auto gload = [](f32x4v& dst, const float* p) {
-        if constexpr (kSetsInAgprs) asm volatile("global_load_dwordx4 %0, %1, off" : "+a"(dst) : "v"(p) : "memory");
-        else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(p) : "memory");
-    };
     float bsum[NAh];   // lanes with q == 0: row sum of dY row r0row + (NT / 4) * j
 #pragma unroll
     for (int n = 0; n < NAh; ++n) bsum[n] = 0.f;
-
+    // address = uniform base (SGPR pair: tile, row group, half) + this lane's 32-bit byte offset: per-lane 64-bit
+    // pointers cost the 256 x 256 kernel the registers it spilled (and a scratch reload's wait drains the queue)
+    auto gload = [](f32x4v& dst, const float* base, unsigned voff) {
+        if constexpr (kSetsInAgprs) asm volatile("global_load_dwordx4 %0, %1, %2" : "+a"(dst) : "v"(voff), "s"(base) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(base) : "memory");
+    };
+    // lane offsets inside a group of NT / 4 rows: row r0row, points 4 q ..; the last X group may run past row K - 1:
+    // those lanes load the last live row and store nothing (split_sub)
+    const unsigned voff = unsigned(r0row * 32 + q * 4) * 4u;
+    unsigned voff_last = voff;
+    {
+        const int row = r0row + (NT / 4) * (NBh - 1);
+        if (row >= K) voff_last = unsigned((K - 1 - (NT / 4) * (NBh - 1)) * 32 + q * 4) * 4u;
+    }
+    static_assert(K - 1 - (NT / 4) * (NBh - 1) >= 0, "the last X group starts at a live row");
     // hs = half-step index inside the slice.  Past the slice's end the last half is loaded again and never used: every
     // half-step then issues NI loads, "two sets are younger" holds from the prologue to the last half-step, and ONE
     // wait statement serves them all (a second form for the tail sat in another branch, and the allocator bridged the
@@ -621,16 +631,15 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
         hs = hs < n_half ? hs : n_half - 1;
         const int64_t tile = t0 + (hs >> 1);
         const int h = int(hs & 1);
-        const float* pa = job.a + (tile * job.a_stride + job.a_row0) * 32 + (4 * h + q) * 4;
+        const float* pa = job.a + (tile * job.a_stride + job.a_row0) * 32 + 16 * h;
 #pragma unroll
-        for (int j = 0; j < NAh; ++j) gload(r[j], pa + (r0row + (NT / 4) * j) * 32);   // all M rows are live (launcher)
-        const float* xb = job.x + tile * job.x_stride * 32 + (4 * h + q) * 4;
+        for (int j = 0; j < NAh; ++j) gload(r[j], pa + (NT / 4) * j * 32, voff);   // all M rows are live (launcher)
+        const float* xb = job.x + tile * job.x_stride * 32 + 16 * h;
 #pragma unroll
         for (int j = 0; j < NBh; ++j) {
-            int row = r0row + (NT / 4) * j;
-            row = row < K ? row : K - 1;   // a thread past the last row loads a live one and stores nothing (split_sub)
-            const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
-            gload(r[NAh + j], xb + src_row * 32);
+            const int row0 = (NT / 4) * j;   // the group's first row: segments are whole groups (launcher)
+            const int src_row0 = row0 < job.x_rows[0] ? job.x_row0[0] + row0 : job.x_row0[1] + row0 - job.x_rows[0];
+            gload(r[NAh + j], xb + src_row0 * 32, j == NBh - 1 ? voff_last : voff);
         }
     };
     // the set `r` is complete once at most the two younger sets' loads are in flight
@@ -828,6 +837,8 @@ static int launch_wgrad_h2p(const WgradJob& job, unsigned slices, hipStream_t st
         attr_set[dev] = true;
     }
     if (job.a_rows != 32 * NW) return NRF_ERR_SHAPE;   // the kernel's dY loads are unconditional
+    // ... and a group of NW * 16 X rows lies in one segment (the clamped tail of the last group aside)
+    if (job.x_rows[0] < 32 * KB && job.x_rows[0] % (NW * 16) != 0) return NRF_ERR_SHAPE;
     wgrad_h2p_kernel<NW, KB><<<dim3(slices), NW * 64, bytes, stream>>>(job);
     return NRF_OK;
 }
