@@ -64,12 +64,19 @@ def allreduce_cell_gradients(grads, touched: torch.Tensor, group=None) -> float:
     added AFTER this call, scaled by world (``KiloTrainStep.step`` does).  On return ``touched`` holds the UNION over
     the ranks (0 / 1): the cells whose gradient may be non-zero now."""
     import torch.distributed as dist
-    from . import kilo_ops
     if not (dist.is_available() and dist.is_initialized()):
         return 1.0
     world = dist.get_world_size(group)
-    if world == 1:
-        return 1.0
+    if world > 1:
+        exchange_cell_gradients(grads, touched, group)
+    return 1.0 / world
+
+
+def exchange_cell_gradients(grads, touched: torch.Tensor, group=None) -> None:
+    """The collectives of ``allreduce_cell_gradients`` (no short cut at world 1, for the same reason as
+    ``gather_rows``)."""
+    import torch.distributed as dist
+    from . import kilo_ops
     union = (touched != 0).to(torch.int32)
     _all_reduce(union, dist.ReduceOp.MAX, group)
     touched.copy_(union)
@@ -78,7 +85,6 @@ def allreduce_cell_gradients(grads, touched: torch.Tensor, group=None) -> float:
         rec = kilo_ops.kilo_cells_gather(grads, cells)
         _all_reduce(rec, dist.ReduceOp.SUM, group)
         kilo_ops.kilo_cells_scatter(rec, cells, grads)
-    return 1.0 / world
 
 
 def render_frame_sharded(render_rows, n_rays: int, rank: int, world: int, group=None, gather: bool = True):
@@ -89,7 +95,15 @@ def render_frame_sharded(render_rows, n_rays: int, rank: int, world: int, group=
     local = render_rows(begin, end - begin)
     if not gather or world == 1:
         return local, (begin, end)
+    return gather_rows(local, n_rays, rank, world, group), (begin, end)
+
+
+def gather_rows(local, n_rays: int, rank: int, world: int, group=None):
+    """The collective of ``render_frame_sharded``: ``local`` holds this rank's slice of every per-ray output; returns
+    the outputs of all ``n_rays`` rays in ray order, on every rank.  (No short cut at world 1: tests/test_gpu_rccl.py
+    runs it through a one-rank RCCL group, the only kind a one-GPU box can form.)"""
     import torch.distributed as dist
+    begin, end = shard_range(n_rays, rank, world)
     # ONE collective per frame: the per-ray columns of every output (9 floats per ray for rgb x 2, depth x 2, acc) are
     # packed side by side; all_gather wants equal shapes, so every rank pads to the largest slice.
     per = (n_rays + world - 1) // world
@@ -116,4 +130,4 @@ def render_frame_sharded(render_rows, n_rays: int, rank: int, world: int, group=
     for k, w in zip(keys, widths):
         out[k] = rows[:, c0:c0 + w].reshape((n_rays,) + tuple(local[k].shape[1:]))
         c0 += w
-    return out, (begin, end)
+    return out
