@@ -89,7 +89,7 @@ def parse(argv=None):
                          "every fixture and the full frame, tests/test_gpu_fp16x2.py, tests/test_gpu_fullsize.py), `dtype` "
                          "says so; bf16x3 = three bf16 terms (all 24 bits), six MFMAs per product; fp32 = the fp32 MFMA "
                          "kernel; bf16 = the bf16 MLP of configs[4], reported under its own metric name.  --mode train runs "
-                         "its matrix work on the bf16x3 kernels unless --dtype fp32")
+                         "its matrix work on the kernels of the same --dtype (fp16x2, bf16x3 or fp32)")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
