@@ -35,7 +35,8 @@ class TrainStep:
         data-gradient chain and the weight-gradient GEMMs on the three-term bf16 kernels (fp32-class: DESIGN 3.7; the
         forward saves the same activations) -- or "fp16x2": the two forward passes on the two-term fp16 kernel
         (same saved activations) and the backward's data-gradient chain on it too, at a power-of-two loss
-        scale the kernel picks from the batch's largest |d raw| (weight-gradient GEMMs on the bf16x3 kernels).
+        scale the kernel picks from the batch's largest |d raw|, and the weight-gradient GEMMs on the fp16 pipe as well
+        (dY scaled per row set from the chain's maxima; the two head layers on a VALU streaming kernel).
         ``backward_dtype``: "bf16x3" or "fp16x2" to choose the chain's kernel separately (default: the forward's)."""
         if forward_dtype not in ("fp32", "bf16x3", "fp16x2"):
             raise ValueError(f"forward_dtype {forward_dtype!r}: expected 'fp32', 'bf16x3' or 'fp16x2'")
