@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--train-dtype", default="fp16x2", choices=["fp32", "bf16x3", "fp16x2"], help="--only train: TrainStep's forward_dtype")
+ap.add_argument("--kilo-dtype", default="fp16x2", choices=["fp32", "fp16x2"], help="--only kilo: KiloRenderer's mlp_dtype")
 ap.add_argument("--only", default="all", choices=["all", "mlp", "composite", "sample", "bf16", "bf16x3", "fp16x2", "kilo", "train"])
 a = ap.parse_args()
 
@@ -35,7 +36,7 @@ if a.only == "kilo":        # KiloNeRF frame (BASELINE configs[3]): march + rout
     net.to(dev)
     c = (torch.arange(256, device=dev, dtype=torch.float32) + 0.5) / 256 * 2 - 1
     occ = ((c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2).sqrt() < 0.75).to(torch.uint8)
-    r = KiloRenderer(net, default_kilo_cfg(), occ)
+    r = KiloRenderer(net, default_kilo_cfg(), occ, mlp_dtype=a.kilo_dtype)
     o, d = ops.raygen(pose_spherical(0.0), 800, 800, focal_from_angle(800), dev)
     for _ in range(a.reps + 1):
         out = r({"xyz": o[None], "viewdirs": d[None]}, is_training=False)
