@@ -113,6 +113,21 @@ def recorded_traffic(dtype: str = "fp32"):
         return None
 
 
+def recorded_kilo_traffic(kind: str):
+    """HBM bytes of the KiloNeRF frame's tiny-MLP stage (route + cell scan + scatter + kilo_mlp kernel, one launch each per
+    frame) from the committed rocprofv3 PMC passes over the same frame (tools/run_pmc.sh ... kilo; FETCH_SIZE x2 +
+    WRITE_SIZE as for the other kernels): profiles/r02_kilo_h2_pmc.json (fp16x2) / r02_kilo_pmc.json (fp32)."""
+    path = os.path.join(ROOT, "profiles", "r02_kilo_pmc.json" if kind == "fp32" else "r02_kilo_h2_pmc.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+        stage = [v["derived"]["hbm_bytes"] for k, v in kernels.items()
+                 if k.startswith(("kilo_route_kernel", "kilo_cell_scan_kernel", "kilo_scatter_kernel", "kilo_mlp_"))]
+        return float(sum(stage)) if len(stage) == 4 else None
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def recorded_composite_traffic():
     """Same for the fine compositing launch (profiles/r01_composite_traffic_pmc.json)."""
     try:
@@ -406,7 +421,9 @@ def kilo_bench(args, dev, rank, world, dist):
             "roofline": {"kernel": "kilo_forward (route + counting sort + %s)" % ("kilo_mlp_kernel" if kind == "fp32" else
                                    "kilo_mlp_h2_kernel: 3 fp16 MFMAs per fp32 product; peak = fp16 peak / 3"), "bound": "mfma",
                          "achieved": flop / (ms["mlp"] * 1e-3) / 1e12, "peak": PEAK_TFLOPS[kind], "unit": "TFLOP/s",
-                         "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / PEAK_TFLOPS[kind], "traffic": None,
+                         "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / PEAK_TFLOPS[kind], "traffic": recorded_kilo_traffic(kind),
+                         "traffic_note": "HBM bytes of the stage's four kernels per frame from the committed PMC passes "
+                                         "(profiles/): ~91 B per evaluated sample, far from the HBM bound",
                          "samples_per_s": n / (ms["mlp"] * 1e-3)},
             "stage_ms": ms}
         if world == 1 and not args.no_cpu_baseline:
