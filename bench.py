@@ -16,12 +16,14 @@ split in contiguous slices over the ranks and one all_gather assembles the frame
 value = rays of the frame / max-over-ranks time per frame (strong scaling, the metric's "ms per
 800x800 frame at 1/2/4/8 MI355X"); the one-view-per-rank rate is carried as `weak_scaling`.
 
-The MLP of the default run is mlp_fp16x2_kernel: fp32 in, fp32 out, fp32 accumulate, each fp32 operand carried as two
-fp16 terms (22 significand bits) and each product as three fp16 MFMAs.  Its distance to float64 is the fp32 reference's
-own on every fixture (0.8-1.1x: an fp32 accumulation of 256 terms loses more than the 2^-22 operand error), it holds
-the 1e-4 bar on every fixture and the full-frame spot check, and `dtype` names it.  `--dtype bf16x3` carries every
-operand exactly (three bf16 terms, six MFMAs per product), `--dtype fp32` runs the fp32 MFMA kernel; the default line
-carries both frames as `also.bf16x3_frame` and `also.fp32_frame`.
+The MLP of the default run is mlp_bf16x3_kernel: the reference's fp32 arithmetic (BASELINE configs[1] "fp32",
+src/models/nerf/network.py:190) -- fp32 in, fp32 out, fp32 accumulate, every fp32 operand carried EXACTLY as three bf16
+terms (3 x 8 = 24 significand bits) and each product as six bf16 MFMAs -- and `dtype` names it.  `--dtype fp32` runs the
+fp32 MFMA kernel (also 24-bit operands); `--dtype fp16x2` is the narrower form (two fp16 terms = 22 significand bits,
+three MFMAs per product: less than the reference's arithmetic, so never the headline).  The default line carries the
+other two frames as `also.fp32_frame` and `also.fp16x2_frame`, and the training step / KiloNeRF frame in the 24-bit
+dtype first (`also.train_step`, `also.kilo_frame`) with their fp16x2 forms beside them (`also.train_step_fp16x2`,
+`also.kilo_frame_fp16x2`).
 
 The same JSON line carries
   roofline      the dominant kernel (MFMA-bound): algorithmic FLOPs of the fp32 problem per launch
@@ -52,7 +54,7 @@ FLOP_PER_POINT = 2 * MACS_PER_POINT
 FP32_MFMA_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0
-DEFAULT_DTYPE = "fp16x2"
+DEFAULT_DTYPE = "bf16x3"
 # MFMA ceiling on the FLOPs of the fp32 problem: the fp16 / bf16 matrix peak divided by the MFMAs one fp32 product takes
 PEAK_TFLOPS = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 6,
                "fp16x2": BF16_MFMA_PEAK_TFLOPS / 3}   # MI355X_MICROARCH.md: fp16 and bf16 dense MFMA peaks are equal
@@ -83,13 +85,13 @@ def parse(argv=None):
                          "--dtype bf16); frame: the ray-sharded headline of `render` alone, without per-stage events")
     ap.add_argument("--views", type=int, default=200, help="testset mode: number of views in the set")
     ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["fp16x2", "bf16x3", "fp32", "bf16"],
-                    help="render mode only: fp16x2 (default) = BASELINE configs[1], the fp32 computation with every MLP "
-                         "operand carried as two fp16 terms (22 significand bits) on the fp16 MFMA, three MFMAs per product, "
-                         "fp32 accumulate (fp32-class: as close to float64 as the fp32 reference and inside the 1e-4 bar on "
-                         "every fixture and the full frame, tests/test_gpu_fp16x2.py, tests/test_gpu_fullsize.py), `dtype` "
-                         "says so; bf16x3 = three bf16 terms (all 24 bits), six MFMAs per product; fp32 = the fp32 MFMA "
-                         "kernel; bf16 = the bf16 MLP of configs[4], reported under its own metric name.  --mode train runs "
-                         "its matrix work on the kernels of the same --dtype (fp16x2, bf16x3 or fp32)")
+                    help="bf16x3 (default) = BASELINE configs[1] in the reference's fp32 arithmetic: every MLP operand carried "
+                         "exactly as three bf16 terms (all 24 significand bits), six bf16 MFMAs per product, fp32 accumulate; "
+                         "fp32 = the fp32 MFMA kernel; fp16x2 = two fp16 terms per operand (22 significand bits, three MFMAs "
+                         "per product: narrower than the reference's arithmetic, reported beside the headline only); bf16 = "
+                         "the bf16 MLP of configs[4], reported under its own metric name.  --mode train runs its matrix work "
+                         "on the kernels of the same --dtype (bf16x3, fp32 or fp16x2); --mode kilo runs the tiny MLPs on the "
+                         "fp32 MFMA kernel unless --dtype fp16x2")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -356,7 +358,7 @@ def kilo_bench(args, dev, rank, world, dist):
     net.to(dev)
     c = (torch.arange(256, device=dev, dtype=torch.float32) + 0.5) / 256 * 2 - 1
     occ = ((c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2).sqrt() < 0.75).to(torch.uint8)
-    kind = "fp32" if args.dtype == "fp32" else "fp16x2"      # the default --dtype: the tiny MLPs on the fp16 matrix cores
+    kind = "fp16x2" if args.dtype == "fp16x2" else "fp32"    # default: the reference's fp32 arithmetic (fp32 MFMA kernel)
     r = KiloRenderer(net, default_kilo_cfg(), occ, mlp_dtype=kind)
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
@@ -784,12 +786,17 @@ def also_block(args, net, dev):
             torch.cuda.empty_cache()
     out["bf16_frame"] = cut(render_bench(sub, net, dev, 0, 1, None, dtype="bf16", steps=5, warmup=1, cpu=False))
     torch.cuda.empty_cache()
-    sub.steps, sub.warmup = 20, 3
-    out["train_step"] = cut(train_bench(sub, copy_network(net, dev), dev, 0, 1, None))
-    torch.cuda.empty_cache()
-    sub.steps, sub.warmup = 20, 3
-    out["kilo_frame"] = cut(kilo_bench(sub, dev, 0, 1, None))
-    torch.cuda.empty_cache()
+    # configs[2] / configs[3] in 24-bit-operand arithmetic first (the reference's: bf16x3 matrix work for the training
+    # step, the fp32 MFMA kernel for the KiloNeRF tiny MLPs), their narrower fp16x2 forms beside them
+    wide = "fp32" if args.dtype == "fp32" else "bf16x3"
+    for key, dtype in (("train_step", wide), ("train_step_fp16x2", "fp16x2")):
+        sub.steps, sub.warmup, sub.dtype = 20, 3, dtype
+        out[key] = cut(train_bench(sub, copy_network(net, dev), dev, 0, 1, None))
+        torch.cuda.empty_cache()
+    for key, dtype in (("kilo_frame", "fp32"), ("kilo_frame_fp16x2", "fp16x2")):
+        sub.steps, sub.warmup, sub.dtype = 20, 3, dtype
+        out[key] = cut(kilo_bench(sub, dev, 0, 1, None))
+        torch.cuda.empty_cache()
     return out
 
 

@@ -9,11 +9,19 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 data unless the name ends in
  *     `_host`;  sizes are element counts;  `stream` is a hipStream_t (NULL = default stream);
- *   - no entry point allocates, frees or synchronises; work is enqueued on `stream`;
- *     scratch is passed in by the caller (nrf_render_workspace_bytes);
+ *   - entry points enqueue work on `stream` and return; scratch is passed in by the caller
+ *     (nrf_*_workspace_bytes), and no entry point allocates, frees, synchronises or keeps state
+ *     between calls -- with exactly THREE documented exceptions:
+ *       1. nrf_kilo_train_forward_backward: on its first call per device it allocates 64 bytes of pinned
+ *          host memory + one event (kept until the process ends), and every call WAITS on the host
+ *          for the batch's sample count (a spin on that pinned word) before it enqueues the rest;
+ *          calls on one device share the word, so calls that overlap on one device race;
+ *       2. nrf_packed_fp16x2_status: copies one status word to the host and waits for `stream`;
+ *       3. nrf_render_static: its workspace is a device array inside the library (per-device
+ *          address resolved on first use), shared by all calls on that device;
  *   - return value: 0 on success, a negative nrf_status otherwise (nrf_strerror gives text);
  *     shapes are validated on the host before any launch;
- *   - thread-safe for distinct streams / buffers; there is no hidden global state.
+ *   - thread-safe for distinct streams / buffers, apart from the three exceptions above.
  */
 #ifndef NERF_AMD_H
 #define NERF_AMD_H
@@ -420,7 +428,7 @@ typedef struct nrf_kilo_train_args {
     float* acc_map;              /* out (n_rays,) */
     float* loss_accum;           /* out: one float, zeroed here, then mse terms added */
     int32_t* touched;            /* out (num_cells,) int32 or NULL: 1 where the batch has samples */
-    int32_t* live;               /* in/out (num_cells,) int32 or NULL: live[c] |= (the batch has samples in c), nrf_kilo_clip_adam's mask */
+    int32_t* live;               /* in/out (num_cells,) int32 or NULL: live[c] |= 3 where the batch has samples in c (nrf_kilo_clip_adam's mask: both bits) */
     int64_t* n_samples;          /* HOST out: samples of this batch */
     int64_t max_samples;
     void* workspace;
@@ -432,13 +440,17 @@ int nrf_kilo_train_forward_backward(const nrf_kilo_train_args* args, nrf_stream_
 
 /* nrf_clip_adam_l2 for the 12 batched KiloNeRF tensors (trainer.py:74-75 + optimizer.py:9-29 over
  * BatchedKiloNeRF's parameters), one block per cell: params / grads / exp_avg / exp_avg_sq are HOST arrays of 12 DEVICE
- * tensors (nrf_kilo_pack_weights order, each 16-byte aligned).  `live` (int32 per cell, or NULL = every cell): cells
- * with live == 0 are skipped in the eight unregularised tensors -- exact, not an approximation, PROVIDED such a
- * cell's gradient and both moments are zero in those tensors (true for a cell no batch has sampled since the optimiser
- * state was zeroed: Adam then computes p - lr * (0 / eps) = p); the caller keeps `live` as the running OR of the
- * cells its batches touched (nrf_kilo_train_args.touched).  The four colour-regularised tensors (the last four) get
- * grads += 2 reg_grad_coeff p (written back) and *loss_accum += reg_loss_coeff sum p^2 in every cell; with both
- * coefficients zero they are treated like the first eight. */
+ * tensors (nrf_kilo_pack_weights order, each 16-byte aligned).  `live` (int32 per cell, or NULL = every tensor of
+ * every cell) is a two-bit mask: bit 0 clear -> the cell's slices of the eight unregularised tensors are skipped,
+ * bit 1 clear -> its slices of the four colour-regularised tensors (the last four) are skipped, unless this call
+ * applies the regulariser (then they are updated in every cell).  Skipping is exact, not an approximation, PROVIDED
+ * the skipped slices' gradient and BOTH Adam moments are zero (Adam then computes p - lr * (0 / eps) = p).  That is
+ * the caller's contract for all twelve tensors: bit 0 | bit 1 (= 3) for every cell a batch has sampled since the
+ * moments were zeroed (nrf_kilo_train_args.live ORs 3 in), bit 1 for EVERY cell from the first call that applied the
+ * regulariser (its gradient 2 l2 p is non-zero everywhere, so every cell has moments in the last four tensors from
+ * then on), and all cells = 3 whenever moments are loaded from elsewhere (a checkpoint's exp_avg / exp_avg_sq).
+ * With the regulariser on, the last four tensors get grads += 2 reg_grad_coeff p (written back) and
+ * *loss_accum += reg_loss_coeff sum p^2 in every cell. */
 int nrf_kilo_clip_adam(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, int num_cells,
                        const int32_t* live, float grad_scale, float clip_value, float lr, float beta1, float beta2, float eps,
                        int step, float reg_grad_coeff, float reg_loss_coeff, float* loss_accum, nrf_stream_t stream);

@@ -18,7 +18,7 @@ NRF_EXPORT const char* nrf_strerror(int status) {
             return "nrf_render_static: n_rays or sample count beyond the library's static scratch "
                    "(NRF_RENDER_STATIC_MAX_RAYS rays, n_coarse + n_importance <= 256); use nrf_render with a workspace";
         case NRF_ERR_RUNTIME: return "a HIP runtime call failed (hipGetDevice / hipGetSymbolAddress)";
-        case NRF_ERR_RANGE: return "fp16x2: a weight lies outside fp16's range (|w| >= 65520 or not finite); use bf16x3 or fp32";
+        case NRF_ERR_RANGE: return "NRF_ERR_RANGE: fp16x2: a weight lies outside fp16's range (|w| >= 65520 or not finite); use bf16x3 or fp32";
         default: return "unknown nrf_status";
     }
 }

@@ -96,15 +96,16 @@ __global__ __launch_bounds__(256) void touched_kernel(const int* __restrict__ hi
     if (i >= num_cells) return;
     const int t = hist[i] != 0;
     if (touched) touched[i] = t;
-    if (live && t) live[i] = 1;
+    if (live && t) live[i] |= 3;   // both of nrf_kilo_clip_adam's bits: all twelve tensors of the cell have a gradient
 }
 
 // ---- optimiser pass over the cell grid ----------------------------------------------------------------------------
 // torch.optim.Adam over all 25.4 M parameters moves 28 B per parameter, and for most of the grid it moves them to
 // compute nothing: a cell that no batch has sampled since the optimiser was created has g = 0, exp_avg = 0 and
 // exp_avg_sq = 0 in its eight unregularised tensors, and Adam's update of such an element is p - lr * (0 / eps) = p,
-// bit for bit.  One block per cell: the unregularised slices only where `live` says the cell has ever had a gradient,
-// the four colour-regularised slices (g = 2 l2 p everywhere) always.  Same arithmetic per element as clip_adam_kernel
+// bit for bit.  One block per cell: the unregularised slices only where bit 0 of `live` says the cell has ever had a
+// gradient; the four colour-regularised slices in every cell when this call applies the regulariser (g = 2 l2 p
+// everywhere), otherwise where bit 1 says they have a gradient or moments (every cell, once a regularised step ran).  Same arithmetic per element as clip_adam_kernel
 // (train.hip); the regulariser folded in as in nrf_clip_adam_l2.
 struct CellAdam {
     float* p[12];
@@ -160,7 +161,8 @@ template <bool REG>
 __global__ __launch_bounds__(256) void kilo_adam_kernel(CellAdam a, const int32_t* __restrict__ live, float* __restrict__ loss) {
     const int cell = blockIdx.x;
     float sq = 0.f;
-    if (!live || live[cell] != 0) {
+    const int mask = live ? live[cell] : 3;   // bit 0: the eight unregularised tensors, bit 1: the four regularised ones
+    if (mask & 1) {
         cell_adam_slice<0, false>(a, cell, sq);
         cell_adam_slice<1, false>(a, cell, sq);
         cell_adam_slice<2, false>(a, cell, sq);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void kilo_adam_kernel(CellAdam a, const int32_
         cell_adam_slice<6, false>(a, cell, sq);
         cell_adam_slice<7, false>(a, cell, sq);
     }
-    if (REG || !live || live[cell] != 0) {   // without a regulariser the last four tensors are like the first eight
+    if (REG || (mask & 2)) {   // without a regulariser in this call: only where they have a gradient or moments (bit 1)
         cell_adam_slice<8, REG>(a, cell, sq);
         cell_adam_slice<9, REG>(a, cell, sq);
         cell_adam_slice<10, REG>(a, cell, sq);
@@ -220,9 +222,14 @@ NRF_EXPORT int nrf_kilo_train_forward_backward(const nrf_kilo_train_args* a, nrf
     rc = nrf_kilo_march_count(a->rays_o, a->rays_d, a->n_rays, a->occ, a->occ_res, a->aabb, a->t_near, a->t_far, a->step,
                               w.counts, w.offsets, w.total, w.march, w.march_bytes, stream);
     if (rc != NRF_OK) return rc;
-    volatile int64_t* count_word = count_host;
-    *count_word = -1;   // a count is never negative: the host below spins on the pinned word itself (a blocking
-                        // hipEventSynchronize sleeps, and its wake-up costs the GPU tens of idle microseconds per step)
+    // The host spins on the pinned word the copy writes (a blocking hipEventSynchronize sleeps, and its wake-up costs
+    // the GPU tens of idle microseconds per step).  Nothing guarantees that an 8-byte device-to-host copy lands as ONE
+    // write, so the word is seeded with all ones and read as two 32-bit halves: it counts as arrived only when NEITHER
+    // half still holds the seed (high half first would otherwise read as 0x00000000FFFFFFFF = 4.29e9 samples).  A
+    // count whose low half really is 0xFFFFFFFF is picked up by the event query below instead.
+    volatile uint32_t* half = reinterpret_cast<volatile uint32_t*>(count_host);
+    half[0] = 0xFFFFFFFFu;
+    half[1] = 0xFFFFFFFFu;
     if (hipMemcpyAsync(count_host, w.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipEventRecord(arrived, stream) != hipSuccess)
         return NRF_ERR_RUNTIME;
@@ -231,7 +238,7 @@ NRF_EXPORT int nrf_kilo_train_forward_backward(const nrf_kilo_train_args* a, nrf
         if (rc != NRF_OK) return rc;
     }
     (void)hipMemsetAsync(a->loss_accum, 0, sizeof(float), stream);
-    for (unsigned spins = 1; *count_word < 0; ++spins) {
+    for (unsigned spins = 1; half[0] == 0xFFFFFFFFu || half[1] == 0xFFFFFFFFu; ++spins) {
         __builtin_ia32_pause();
         if ((spins & 0xfff) == 0) {   // every few microseconds: has the stream failed, or finished without the word showing up?
             const hipError_t q = hipEventQuery(arrived);
@@ -243,7 +250,7 @@ NRF_EXPORT int nrf_kilo_train_forward_backward(const nrf_kilo_train_args* a, nrf
         }
     }
     (void)hipGetLastError();   // hipErrorNotReady from the queries is not an error
-    const int64_t n = *count_word;
+    const int64_t n = int64_t((uint64_t(half[1]) << 32) | uint64_t(half[0]));
     if (n < 0) return NRF_ERR_RUNTIME;
     *a->n_samples = n;
     if (n > a->max_samples) return NRF_ERR_WORKSPACE;   // *n_samples says how many the batch has: size for that, call again

@@ -1006,7 +1006,7 @@ NRF_EXPORT int64_t nrf_mlp_backward_workspace_bytes(int64_t n_rays, int n_sample
 }
 
 // packed_t_x3 != nullptr: the data-gradient chain on the three-term bf16 kernel (mlp_bf16x3.hip) instead of mlp_dgrad_kernel
-// packed_t_h2 != nullptr: the chain on the two-term fp16 kernel (mlp_fp16x2.hip); its weight-gradient GEMMs are the bf16x3 ones
+// packed_t_h2 != nullptr: the chain on the two-term fp16 kernel (mlp_fp16x2.hip) and the weight-gradient GEMMs on wgrad_h2p_kernel
 static int mlp_backward_impl(const float* packed, const float* packed_t, const void* packed_t_x3, const float* grad_raw,
                              const float* acts, const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
                              int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream_, const void* packed_t_h2 = nullptr) {
@@ -1144,7 +1144,8 @@ NRF_EXPORT int nrf_mlp_backward_bf16x3(const float* packed, const void* packed_t
 }
 
 // nrf_mlp_backward with the data-gradient chain on the two-term fp16 kernel at a loss scale chosen on the device
-// (mlp_fp16x2.hip: mlp_dgrad_h2_kernel) and the weight-gradient GEMMs on the three-term bf16 kernels.
+// (mlp_fp16x2.hip: mlp_dgrad_h2_kernel) and the weight-gradient GEMMs on the fp16 pipe as well (wgrad_h2p_kernel: dY scaled
+// per row set from the chain's maxima; the two head layers on head_wgrad_kernel).
 NRF_EXPORT int nrf_mlp_backward_fp16x2(const float* packed, const void* packed_t_h2, const float* grad_raw, const float* acts,
                                        const uint32_t* masks, int64_t n_rays, int n_samples, void* workspace,
                                        int64_t workspace_bytes, float* grad_flat, nrf_stream_t stream) {

@@ -25,12 +25,18 @@ import torch
 class GridEstimator:
     def __init__(self, owner, aabb, resolution, active=None):
         self.owner = owner
-        self.aabb = [float(v) for v in aabb]
+        # `aabb`: six floats, or a callable returning them -- the KiloNeRF box lives in the network's registered buffers,
+        # which load_state_dict / load_network overwrite AFTER the renderer is constructed, so it is read per update
+        self._aabb = aabb if callable(aabb) else [float(v) for v in aabb]
         self.resolution = [int(r) for r in resolution]
         self.cells = self.resolution[0] * self.resolution[1] * self.resolution[2]
         self.occs = None                     # (cells,) float32 EMA of the evaluated density, created on first update
         self._active = active or (lambda: True)
         self.updates = 0
+
+    @property
+    def aabb(self):
+        return [float(v) for v in (self._aabb() if callable(self._aabb) else self._aabb)]
 
     # nerfacc's attribute: volumn_renderer.py:54 assigns it, callers read it
     @property
@@ -80,8 +86,9 @@ class GridEstimator:
                 occupied = occupied[torch.randint(occupied.numel(), (quarter,), device=dev)]
             idx = torch.cat([uniform, occupied])
         res = torch.tensor(self.resolution, dtype=torch.float32, device=dev)
-        lo = torch.tensor(self.aabb[:3], dtype=torch.float32, device=dev)
-        hi = torch.tensor(self.aabb[3:], dtype=torch.float32, device=dev)
+        aabb = self.aabb
+        lo = torch.tensor(aabb[:3], dtype=torch.float32, device=dev)
+        hi = torch.tensor(aabb[3:], dtype=torch.float32, device=dev)
         x = (self._grid_coords(idx) + torch.rand((idx.numel(), 3), device=dev)) / res
         x = lo + x * (hi - lo)
         occ = occ_eval_fn(x).reshape(-1).to(torch.float32)

@@ -73,12 +73,25 @@ class KiloTrainStep:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.t = 0
-        # cells that have had a gradient since the moments were zeroed: everywhere else the eight unregularised
-        # tensors have g = m = v = 0 and Adam's update is the identity, so the optimiser pass skips them
+        # nrf_kilo_clip_adam's two-bit mask per cell.  Bit 0: the cell has had a gradient since the moments were zeroed
+        # (elsewhere the eight unregularised tensors have g = m = v = 0 and Adam's update is the identity, so the pass
+        # skips them); bit 1: the same for the four colour-regularised tensors, whose moments are non-zero in EVERY
+        # cell from the first regularised step on (`_reg_moments`).
         self.live = torch.zeros(self.params[0].shape[0], dtype=torch.int32, device=self.device)
+        self._reg_moments = False
         views = lambda flat: [flat[g.storage_offset():g.storage_offset() + g.numel()].view(g.shape) for g in self.grads]  # noqa: E731
         self._adam_ptrs = tuple(kilo_ops.ParamPointers(x) for x in (self.params, self.grads, views(self.exp_avg),
                                                                     views(self.exp_avg_sq)))
+
+    def load_optimizer_state(self, exp_avg, exp_avg_sq, t: int):
+        """Adam moments from elsewhere (the reference's resume: net_utils.py:288-322 restores 'optim'): flat fp32
+        tensors in this step's parameter order.  Nothing is known about which cells they are zero in, so the optimiser
+        pass stops skipping (every cell live in both bits)."""
+        self.exp_avg.copy_(exp_avg.reshape(-1))
+        self.exp_avg_sq.copy_(exp_avg_sq.reshape(-1))
+        self.t = int(t)
+        self.live.fill_(3)
+        self._reg_moments = True
 
     def _reachable_cells(self, occ, res):
         """int32 mask over the cells: 1 where some occupancy voxel inside the cell is set.  A hint, not a contract (the
@@ -147,7 +160,7 @@ class KiloTrainStep:
         if sparse:
             # DDP semantics (mean gradient) with a compact exchange: only cells some rank sampled travel
             scale = allreduce_cell_gradients(self.grads, self.touched, self.group)
-            self.live.bitwise_or_(self.touched)                  # (now the union over the ranks)
+            self.live.bitwise_or_(self.touched * 3)              # (now the union over the ranks; both mask bits)
         else:
             scale = allreduce_gradients(self.grad, self.group)   # ONE flat sum all-reduce, mean in the kernel
             if self.world > 1:
@@ -158,6 +171,11 @@ class KiloTrainStep:
         # term this rank's own.  self.grad ends as nrf_l2_reg would have left it.
         reg = self._reg_pending
         self._reg_pending = False
+        if reg and not self._reg_moments:
+            # from this step on every cell has moments in the four regularised tensors: a later step WITHOUT the
+            # regulariser (fine-tuning without reset_optimizer) must keep updating them everywhere, as torch Adam does
+            self.live.bitwise_or_(2)
+            self._reg_moments = True
         kilo_ops.kilo_clip_adam(*self._adam_ptrs, self.t, live=live, lr=self.lr, clip_value=self.clip, grad_scale=scale,
                                 reg_grad_coeff=self.l2_reg * self.world if reg else 0.0,
                                 reg_loss_coeff=self.l2_reg if reg else 0.0, loss_accum=self.loss)

@@ -270,7 +270,7 @@ class KiloRenderer(nn.Module):
         # trainer.py:58-66 drives `renderer.estimator.update_every_n_steps(step, occ_eval_fn)` every iteration; the
         # reference's estimator re-estimates the grid from the student's density while training (nerf_amd/estimator.py)
         from .estimator import GridEstimator
-        self.estimator = GridEstimator(self, self.view.grid()[0], self.occ_grid_resolution)
+        self.estimator = GridEstimator(self, lambda: self.view.grid()[0], self.occ_grid_resolution)
         if occ_grid is not None:
             self.set_occ_grid(occ_grid)
         elif ref_cfg is not None:

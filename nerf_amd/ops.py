@@ -355,7 +355,7 @@ def mlp_forward_rays_train(packed, rays_o, rays_d, z, kind: str = "fp32"):
           "fp16x2": L.nrf_mlp_forward_rays_train_fp16x2}[kind]
     with torch.cuda.device(dev):
         check(fn(_ptr(packed), _ptr(rays_o), _ptr(rays_d), _ptr(z), stride, R, S, _ptr(raw), _ptr(acts), _ptr(masks),
-                 _stream(raw)), "nrf_mlp_forward_rays_train" + ("" if kind == "fp32" else "_bf16x3"))
+                 _stream(raw)), "nrf_mlp_forward_rays_train" + ("" if kind == "fp32" else "_" + kind))
     return raw, acts, masks
 
 

@@ -54,8 +54,8 @@ class _RenderTrainFn(torch.autograd.Function):
         white = renderer.white_bkgd > 0
         # mlp_dtype "bf16x3": both forward passes, the data-gradient chain and the weight-gradient GEMMs on the three-term
         # bf16 kernels (fp32-class); the fp32 pack still supplies the head rows of the backward
-        # "fp16x2": forward passes and the data-gradient chain on the two-term fp16 kernels (the chain at a
-        # loss scale it picks itself), weight-gradient GEMMs on the bf16x3 kernels
+        # "fp16x2": forward passes, the data-gradient chain (at a loss scale it picks itself) and the weight-gradient
+        # GEMMs (wgrad_h2p_kernel, dY scaled per row set) all on the two-term fp16 kernels
         kind = renderer.mlp_dtype
         bkind = kind
         pc, pc_t = renderer._packed_model("model", dev), renderer._packed_model_t("model", dev, bkind)
@@ -99,7 +99,7 @@ class Renderer(nn.Module):
     """``mlp_dtype``: "fp32" (default, the reference's precision), "bf16x3" (fp32-class results from three-term bf16
     operand splits on the bf16 matrix cores), "fp16x2" (fp32-class results from two-term fp16 operand splits, 22-bit
     operands, for networks whose weights and activations lie in fp16's range; under autograd its backward runs on the
-    bf16x3 kernels) or "bf16" (BASELINE configs[4]: the MLP on the bf16
+    fp16x2 kernels too, at power-of-two scales chosen on the device) or "bf16" (BASELINE configs[4]: the MLP on the bf16
     matrix cores, inference only -- training runs with "fp32", "bf16x3" or "fp16x2"; ``cfg.task_arg.mlp_dtype`` is read when the
     argument is None)."""
 
@@ -137,6 +137,7 @@ class Renderer(nn.Module):
         self.max_rays_per_call = 1 << 20
         self._packed = {}      # model name -> (version key, packed tensor)
         self._packed_t = {}    # model name -> (version key, transposed stream for the backward)
+        self._repacks = {}     # fp16x2 slots: repack count (range-check cadence)
         self._bwd_ws = None
         self._bins = None
         self._workspace = None
@@ -237,7 +238,15 @@ class Renderer(nn.Module):
         buf = hit[1] if hit is not None and hit[1].device == torch.device(device) else None
         ws = [p if p.device == torch.device(device) else p.to(device) for p in params[0::2]]
         bs = [p if p.device == torch.device(device) else p.to(device) for p in params[1::2]]
-        buf = _PACK[kind](ws, bs, out=buf)
+        if kind == "fp16x2":
+            # the packer's range check waits for the stream: always for inference (weights are packed once), but under
+            # autograd -- a repack per training step -- only on the first repack and every 64th after it; in between a
+            # weight that has outgrown fp16 shows as NaN outputs (TrainStep does the same)
+            n = self._repacks.get(slot, 0)
+            self._repacks[slot] = n + 1
+            buf = _PACK[kind](ws, bs, out=buf, check_range=(not torch.is_grad_enabled()) or n % 64 == 0)
+        else:
+            buf = _PACK[kind](ws, bs, out=buf)
         self._packed[slot] = (key, buf)
         return buf
 

@@ -30,20 +30,25 @@ def exponential_lr(base_lr: float, epoch: int, decay_epochs: int = 500, gamma: f
 
 class TrainStep:
     def __init__(self, net, device, near=2.0, far=6.0, n_coarse=64, n_importance=128, white_bkgd=True,
-                 lr=5e-4, clip_value=40.0, process_group=None, forward_dtype="fp32", backward_dtype=None):
+                 lr=5e-4, clip_value=40.0, process_group=None, forward_dtype="fp32", backward_dtype=None,
+                 range_check_every: int = 64):
         """``forward_dtype``: "fp32" (the fp32 MFMA kernels), "bf16x3" -- both forward passes, the backward's
         data-gradient chain and the weight-gradient GEMMs on the three-term bf16 kernels (fp32-class: DESIGN 3.7; the
         forward saves the same activations) -- or "fp16x2": the two forward passes on the two-term fp16 kernel
         (same saved activations) and the backward's data-gradient chain on it too, at a power-of-two loss
         scale the kernel picks from the batch's largest |d raw|, and the weight-gradient GEMMs on the fp16 pipe as well
         (dY scaled per row set from the chain's maxima; the two head layers on a VALU streaming kernel).
-        ``backward_dtype``: "bf16x3" or "fp16x2" to choose the chain's kernel separately (default: the forward's)."""
+        ``backward_dtype``: "bf16x3" or "fp16x2" to choose the chain's kernel separately (default: the forward's).
+        ``range_check_every`` (fp16x2 only): every that many steps -- and on the first -- the packer's status word is
+        read back (nrf_packed_fp16x2_status: one wait on the stream) and a weight that has outgrown fp16's range raises
+        NrfError naming NRF_ERR_RANGE at that step, instead of surfacing as a NaN loss some steps later; 0 = never."""
         if forward_dtype not in ("fp32", "bf16x3", "fp16x2"):
             raise ValueError(f"forward_dtype {forward_dtype!r}: expected 'fp32', 'bf16x3' or 'fp16x2'")
         self.backward_dtype = backward_dtype or forward_dtype
         if self.backward_dtype not in ("fp32", "bf16x3", "fp16x2") or (self.backward_dtype == "fp32") != (forward_dtype == "fp32"):
             raise ValueError(f"backward_dtype {backward_dtype!r} with forward_dtype {forward_dtype!r}")
         self.forward_dtype = forward_dtype
+        self.range_check_every = int(range_check_every)
         self.net = net
         self.device = torch.device(device)
         self.n_coarse, self.n_importance, self.white = n_coarse, n_importance, bool(white_bkgd)
@@ -85,8 +90,11 @@ class TrainStep:
             self._packed[k] = ops.pack_weights(ws, bs, out=self._packed[k])
             if self.forward_dtype == "bf16x3":
                 self._packed_x3[k] = ops.pack_weights_bf16x3(ws, bs, out=self._packed_x3[k])
-            elif self.forward_dtype == "fp16x2":   # no range check here (it waits for the stream): a weight beyond fp16
-                self._packed_x3[k] = ops.pack_weights_fp16x2(ws, bs, out=self._packed_x3[k], check_range=False)  # -> NaN loss
+            elif self.forward_dtype == "fp16x2":
+                # the range check waits for the stream, so it runs every `range_check_every` steps only; between two
+                # checks a weight beyond fp16 shows as a NaN loss (the kernels return NaN for such a stream)
+                due = self.range_check_every > 0 and self.t % self.range_check_every == 0
+                self._packed_x3[k] = ops.pack_weights_fp16x2(ws, bs, out=self._packed_x3[k], check_range=due)
             if self.backward_dtype == "bf16x3":
                 self._packed_t[k] = ops.pack_weights_transposed_bf16x3(ws, out=self._packed_t[k])
             elif self.backward_dtype == "fp16x2":

@@ -34,6 +34,17 @@ def test_plain_start_spawns_n_ranks(n):
     assert lines[0]["n_gpus"] == n and lines[0]["dry_run"] is True and lines[0]["value"] is None
 
 
+@pytest.mark.parametrize("mode", ["render", "train", "testset"])
+def test_eight_rank_dry_run_of_every_scaled_mode(mode):
+    """The driver's SCALE run is `--gpus 8`: eight ranks rendezvous, barrier and reduce their clocks for each mode that
+    has a multi-GPU form (configs[1] ray-sharded frame, configs[2] data-parallel step, configs[4] test set)."""
+    p = run([sys.executable, BENCH, "--gpus", "8", "--mode", mode, "--steps", "2", "--warmup", "1"], {"NRF_BENCH_DRY_RUN": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["n_gpus"] == 8 and lines[0]["mode"] == mode and lines[0]["backend"] == "gloo"
+
+
 def test_torchrun_start_uses_its_world():
     p = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
              "--master-port", "29631", BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], {"NRF_BENCH_DRY_RUN": "1"})

@@ -466,7 +466,7 @@ def test_kilo_clip_adam_equals_flat_adam_and_skips_exactly(dev):
         for c in touched:                                  # data gradients only in the sampled cells, all 12 tensors
             for t in gv:
                 t[c] = torch.randn(t[c].shape, device=dev, generator=g) * 30
-        live[torch.tensor(touched, device=dev)] = 1
+        live[torch.tensor(touched, device=dev)] = 3           # both mask bits, as nrf_kilo_train_args.live ORs them in
         A[1].copy_(grad), B[1].copy_(grad)
         la.zero_(), lb.zero_()
         ops.clip_adam(A[0], A[1], A[2], A[3], step, lr=1e-2, clip_value=40.0, grad_scale=0.5, reg_begin=reg_begin,
@@ -480,12 +480,55 @@ def test_kilo_clip_adam_equals_flat_adam_and_skips_exactly(dev):
     assert int(dead.sum()) == cells - 5
     for t0, t1 in zip(views(p0)[:8], views(B[0])[:8]):
         assert torch.equal(t0[dead], t1[dead])             # never sampled, not regularised: untouched
-    # no regulariser (fine-tuning stage), live = None: plain Adam over all twelve tensors
-    A[1].normal_(generator=g), B[1].copy_(A[1])
+    # A step WITHOUT the regulariser after regularised ones (fine-tuning without a fresh optimiser, or moments restored
+    # from a checkpoint): the four regularised tensors carry moments in EVERY cell by now, so the caller's contract is
+    # bit 1 everywhere (KiloTrainStep sets it on its first regularised step) and the pass must keep updating them from
+    # momentum in never-sampled cells exactly as flat Adam does, while tensors 0..7 of those cells stay skipped.
+    live |= 2
+    grad = torch.zeros(n, device=dev)
+    gv = views(grad)
+    for t in gv:
+        t[17] = torch.randn(t[17].shape, device=dev, generator=g)
+    A[1].copy_(grad), B[1].copy_(grad)
+    before = B[0].clone()
     ops.clip_adam(A[0], A[1], A[2], A[3], 4, lr=1e-2, clip_value=40.0)
-    kilo_ops.kilo_clip_adam(*ptrs, 4, live=None, lr=1e-2, clip_value=40.0)
+    kilo_ops.kilo_clip_adam(*ptrs, 4, live=live, lr=1e-2, clip_value=40.0)
+    for x, y, name in zip(A, B, ("params", "grads", "exp_avg", "exp_avg_sq")):
+        assert torch.equal(x, y), name
+    for t0, t1 in zip(views(before)[8:], views(B[0])[8:]):
+        assert not torch.equal(t0[dead], t1[dead])         # momentum alone moved them, as in torch.optim.Adam
+    # live = None: plain Adam over all twelve tensors of every cell
+    A[1].normal_(generator=g), B[1].copy_(A[1])
+    ops.clip_adam(A[0], A[1], A[2], A[3], 5, lr=1e-2, clip_value=40.0)
+    kilo_ops.kilo_clip_adam(*ptrs, 5, live=None, lr=1e-2, clip_value=40.0)
     for x, y in zip(A, B):
         assert torch.equal(x, y)
+
+
+def test_fine_tuning_step_after_regularised_distillation_keeps_the_momentum(dev):
+    """KiloTrainStep: two distillation steps with l2_reg > 0, then a 'fine-tuning' step WITHOUT reset_optimizer (and
+    with the per-cell `live` mask in use).  Every cell has non-zero Adam moments in the four colour-regularised tensors
+    by then; torch.optim.Adam keeps moving them, so the per-cell pass must too -- checked against the flat
+    nrf_clip_adam on a copy of the same buffers."""
+    from nerf_amd import ops
+    from nerf_amd.kilo_train import KiloTrainStep
+    sd, net, r, occ = _net_and_renderer(dev, seed=9)
+    o, d = _rays()
+    rng = np.random.default_rng(11)
+    t_rgb = _t(rng.uniform(size=(len(o), 3)).astype(np.float32), dev)
+    t_alpha = _t(rng.uniform(size=(len(o), 1)).astype(np.float32), dev)
+    step = KiloTrainStep(r, dev, l2_reg=1e-3)
+    for _ in range(2):
+        step.step(_t(o, dev), _t(d, dev), t_rgb, t_alpha, stage="distillation")
+    assert bool((step.live & 2).all()) and int((step.live & 1).sum()) < step.live.numel()
+    p, m, v = step.flat.clone(), step.exp_avg.clone(), step.exp_avg_sq.clone()
+    step.step(_t(o, dev), _t(d, dev), t_rgb, None, stage="fine-tuning")
+    g = step.grad.clone()
+    ops.clip_adam(p, g, m, v, 3, lr=step.lr, clip_value=step.clip)
+    assert torch.equal(p, step.flat) and torch.equal(m, step.exp_avg) and torch.equal(v, step.exp_avg_sq)
+    # ... and moments loaded from elsewhere switch the skipping off altogether
+    step.load_optimizer_state(m, v, 3)
+    assert bool((step.live == 3).all())
 
 
 def test_fused_call_grows_its_workspace_and_handles_empty_batches(dev):
@@ -524,4 +567,4 @@ def test_fused_call_grows_its_workspace_and_handles_empty_batches(dev):
             assert torch.equal(p0, p1) and torch.all(g == 0)          # no samples, no regulariser: untouched
         else:
             assert torch.allclose(g, 2e-3 * p0, rtol=1e-6, atol=1e-12) and not torch.equal(p0, p1)
-    assert int(step2.live.sum()) == 0
+    assert int((step2.live & 1).sum()) == 0 and bool((step2.live & 2).all())   # no cell sampled; regularised tensors live everywhere

@@ -88,8 +88,8 @@ def _named_flat(ts):
 
 @pytest.mark.parametrize("forward_dtype", ["fp32", "bf16x3", "fp16x2"])
 def test_gradients_of_4096_rays_match_oracle_autograd(case, forward_dtype):
-    """(bf16x3: forward passes, data-gradient chain and weight-gradient GEMMs on the three-term bf16 kernels; fp16x2: the
-    forward passes on the two-term fp16 kernel, the backward as bf16x3 -- same bars.)"""
+    """(bf16x3: forward passes, data-gradient chain and weight-gradient GEMMs on the three-term bf16 kernels; fp16x2: all
+    three on the two-term fp16 kernels, the backward at device-chosen power-of-two scales -- same bars.)"""
     net, ts, args = _train_step(case, forward_dtype=forward_dtype)
     ts.forward_backward(*args)
     assert abs(float(ts.loss) - case["loss"]) < 1e-5, (float(ts.loss), case["loss"])

@@ -162,3 +162,66 @@ def test_cell_gradient_exchange_single_process_is_identity():
     from nerf_amd.parallel import allreduce_cell_gradients
     g = [torch.ones(4, 2)]
     assert allreduce_cell_gradients(g, torch.ones(4, dtype=torch.int32)) == 1.0 and torch.all(g[0] == 1)
+
+
+# ---- eight ranks: the node the scaling bench runs on (8 x MI355X), rehearsed on the CPU -------------------------------
+def _eight_rank_worker(rank, world, port, q):
+    """Everything `bench.py --gpus 8` does between its ranks, on gloo: (a) one 800x800 view ray-sharded over 8 ranks and
+    assembled on every rank, for a ray count the ranks divide (640,000: 80,000 each) and one they do not (640,001: the
+    padding path of gather_rows); (b) the 200-view test set dealt by view_schedule, every view rendered exactly once,
+    25 per rank; (c) three data-parallel steps -- flat-gradient all-reduce, mean, clip, Adam -- with the replicas
+    bit-identical at the end."""
+    from nerf_amd.parallel import allreduce_gradients, gather_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = {}
+        # (a)
+        for n_rays in (640000, 640001):
+            out, span = render_frame_sharded(_fake_render, n_rays, rank, world, gather=True)
+            ref = _fake_render(0, n_rays)
+            ok[f"frame_{n_rays}"] = (span == shard_range(n_rays, rank, world)
+                                     and all(out[k].shape == ref[k].shape and torch.equal(out[k], ref[k]) for k in ref))
+        b, e = shard_range(640001, rank, world)
+        ok["uneven_slices"] = (e - b) == (80001 if rank == 0 else 80000)
+        # (b) every rank "renders" its views (a fake renderer: one row per view carrying the view number and the rank)
+        mine = [v for v, _ in view_schedule(200, rank, world)]
+        ok["views_per_rank"] = len(mine) == 25 and mine == list(range(rank, 200, world))
+        rows = {"view": torch.tensor(mine, dtype=torch.float32), "rank": torch.full((len(mine),), float(rank))}
+        allv = gather_rows(rows, 200, rank, world)                   # rank r's rows land at [25 r, 25 r + 25)
+        ok["every_view_once"] = (sorted(allv["view"].tolist()) == [float(v) for v in range(200)]
+                                 and all(int(v) % world == int(r) for v, r in zip(allv["view"].tolist(), allv["rank"].tolist())))
+        # (c)
+        n = 1191688                                                  # both NeRF models, SURVEY 8a row 12
+        p = torch.zeros(n, requires_grad=True)
+        opt = torch.optim.Adam([p], lr=5e-4)
+        for step in range(3):
+            g = torch.Generator().manual_seed(1000 * step + rank)    # every rank its own batch -> its own gradient
+            flat = torch.randn(n, generator=g) * 50
+            scale = allreduce_gradients(flat)
+            ok[f"scale_{step}"] = scale == 1.0 / world
+            p.grad = flat * scale                                    # trainer.py:73-75: mean, then clip, then Adam
+            torch.nn.utils.clip_grad_value_([p], 40.0)
+            opt.step()
+        gathered = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(gathered, p.detach())
+        ok["replicas_identical"] = all(torch.equal(gathered[0], t) for t in gathered) and bool(p.detach().abs().max() > 0)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_rehearsal_frame_views_and_gradient_steps():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    world = 8
+    procs = [ctx.Process(target=_eight_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == list(range(world))
+    for rank, ok in res.items():
+        assert all(ok.values()), (rank, {k: v for k, v in ok.items() if not v})
