@@ -393,6 +393,24 @@ def mlp_backward(packed, packed_t, g_raw, acts, masks, workspace: torch.Tensor |
     return flat
 
 
+def backward_scale_block(workspace: torch.Tensor, n_rays: int, n_samples: int) -> torch.Tensor:
+    """The fp16x2 backward's scale block (64 uint32 words as an int32 tensor, a copy) as the last nrf_mlp_backward_fp16x2
+    call with these sizes left it in ``workspace``: word 0 holds the bits of max |d raw| of the batch, from which the
+    chain picked its power-of-two loss scale (``loss_scale_exponent``), words 1.. the maxima of the scaled dY row sets
+    (csrc/split2h.h: kGmax*).  No synchronisation: a device-side copy on the current stream."""
+    need = int(lib().nrf_mlp_backward_workspace_bytes(n_rays, n_samples))
+    return workspace[need - 256:need].view(torch.int32).clone()
+
+
+def loss_scale_exponent(max_bits: int, target: int = 4) -> int:
+    """S of the chain's loss scale 2^S (csrc/split2h.h: scale_exponent with kChainScaleTarget = 4: max |d raw| lands in
+    [16, 32)); 0 for a zero, subnormal or non-finite maximum."""
+    e = (int(max_bits) >> 23) & 0xFF
+    if e in (0, 255):
+        return 0
+    return max(-100, min(100, target - (e - 127)))
+
+
 def split_flat_grad(flat: torch.Tensor):
     """flat (595,844,) -> 12 (weight, bias) pairs shaped like LAYER_SHAPES (views, no copies)."""
     out, o = [], 0

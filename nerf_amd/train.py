@@ -84,6 +84,9 @@ class TrainStep:
         self._packed_x3 = [None, None]
         self._ws = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # fp16x2 backward: with `log_scales` set (a list), every step appends the (coarse, fine) scale blocks of its two
+        # chains (ops.backward_scale_block: device tensors, no wait) -- the loss scale picked per step is word 0
+        self.log_scales = None
 
     def _pack(self):
         for k, (ws, bs) in enumerate(self.models):
@@ -123,9 +126,13 @@ class TrainStep:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         g_raw_c = ops.composite_backward(raw_c, zc, self.white, g_c)
         ops.mlp_backward(pc, pc_t, g_raw_c, acts_c, masks_c, self._ws, out=self.grad[:n], kind=self.backward_dtype)
+        log = self.log_scales is not None and self.backward_dtype == "fp16x2"
+        blk_c = ops.backward_scale_block(self._ws, raw_c.shape[0], raw_c.shape[1]) if log else None
         del g_raw_c, acts_c, masks_c, raw_c
         g_raw_f = ops.composite_backward(raw_f, z_f, self.white, g_f)
         ops.mlp_backward(pf, pf_t, g_raw_f, acts_f, masks_f, self._ws, out=self.grad[n:], kind=self.backward_dtype)
+        if log:
+            self.log_scales.append((blk_c, ops.backward_scale_block(self._ws, raw_f.shape[0], raw_f.shape[1])))
         return {"coarse_rgb_map": c_rgb, "fine_rgb_map": f_rgb, "fine_depth_map": f_depth, "alpha_map": f_acc}
 
     def step(self, rays_o, rays_d, gt, u, u2, u_coarse=None, u_fine=None):

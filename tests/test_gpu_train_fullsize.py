@@ -17,16 +17,20 @@ R, NC, NI = 4096, 64, 128
 H = W = 800
 
 
-@pytest.fixture(scope="module")
-def case():
+def _make_case(realistic: bool):
     """Inputs of one step + the oracle's loss and gradients (torch autograd, accumulated over 512-ray chunks: the loss
-    is a mean over rays, so the chunks' `sum / (3 R)` terms add up to it exactly as autograd would)."""
+    is a mean over rays, so the chunks' `sum / (3 R)` terms add up to it exactly as autograd would).
+
+    ``realistic``: gt is not uniform noise but the oracle's own fine render of a copy of the network whose weights are
+    perturbed by 1 % -- the residuals are then systematic, as those of a network in training are, and no gradient
+    tensor is a pure cancellation of 1.05 M random-signed terms (no float64 yardstick is computed for this case: the
+    plain bar must hold on its own)."""
     from nerf_amd import ops
     from nerf_amd.camera import focal_from_angle, pose_spherical
     from nerf_amd.weights import make_state_dict
     from oracle import nerf_oracle as O
     dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(20)
+    g = torch.Generator().manual_seed(21 if realistic else 20)
     # pixels of the central 400 x 400 window: rays that cross the scene box, like a cropped training batch
     pix = (torch.randint(200, 600, (R,), generator=g) * W + torch.randint(200, 600, (R,), generator=g)).to(torch.int64)
     rays_o, rays_d = ops.raygen(pose_spherical(30.0), H, W, focal_from_angle(W), dev, pixel_index=pix.to(dev))
@@ -34,9 +38,15 @@ def case():
            "gt": torch.rand(R, 3, generator=g), "u": torch.rand(R, NI, generator=g), "u2": torch.rand(R, NI, generator=g),
            "u_coarse": torch.rand(R, NC, generator=g), "u_fine": torch.rand(R, NI, generator=g)}
     sd0 = make_state_dict(0, 30.0, 2.0)
+    o, d = rays_o.cpu(), rays_d.cpu()
+    if realistic:
+        teacher = {k: v * (1.0 + 0.01 * torch.randn(v.shape, generator=g)) for k, v in sd0.items()}
+        with torch.no_grad():
+            inp["gt"] = torch.cat([O.render(teacher, o[r0:r0 + 512], d[r0:r0 + 512], u=inp["u"][r0:r0 + 512].numpy(),
+                                            u2=inp["u2"][r0:r0 + 512].numpy(), u_coarse=inp["u_coarse"][r0:r0 + 512].numpy(),
+                                            u_fine=inp["u_fine"][r0:r0 + 512].numpy())["fine_rgb_map"] for r0 in range(0, R, 512)])
     sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
     sd64 = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
-    o, d = rays_o.cpu(), rays_d.cpu()
     loss = 0.0
     zf = []
     for r0 in range(0, R, 512):
@@ -47,6 +57,8 @@ def case():
         part.backward()
         loss += float(part)
         zf.append(out["z_fine"])
+        if realistic:
+            continue
         # the yardstick: the same loss at the same sample depths (constants under autograd, volume_renderer.py:381-390)
         # evaluated in float64 -- what both fp32 gradients approximate; separates summation noise from a wrong kernel
         o64, d64, gt64 = o[s].double(), d[s].double(), inp["gt"][s].double()
@@ -58,8 +70,18 @@ def case():
             part64 = part64 + ((rgb - gt64) ** 2).sum() / (3 * R)
         part64.backward()
     grads = {k: v.grad.clone() for k, v in sd.items()}
-    grads64 = {k: v.grad.clone() for k, v in sd64.items()}
+    grads64 = None if realistic else {k: v.grad.clone() for k, v in sd64.items()}
     return {"dev": dev, "inp": inp, "sd0": sd0, "loss": loss, "grads": grads, "grads64": grads64, "z_fine": torch.cat(zf)}
+
+
+@pytest.fixture(scope="module")
+def case():
+    return _make_case(False)
+
+
+@pytest.fixture(scope="module")
+def case_realistic():
+    return _make_case(True)
 
 
 def _train_step(case, rays=slice(None), forward_dtype="fp32"):
@@ -86,40 +108,85 @@ def _named_flat(ts):
     return out
 
 
+# How many of the 48 gradient tensors may need a bar other than the plain one (2e-4 of the tensor's own max against the
+# oracle's fp32 autograd) in the random-gt case, per dtype: (float64 yardstick, absolute floor).  Measured numbers of
+# round 3, kept as ceilings: a change that pushes more tensors off the plain bar fails here even if every tensor still
+# passes one of the three.
+# (measured on the box: fp32 39 plain / 9 float64 / 0 floor; bf16x3 28 / 19 / 1 -- model_fine.alpha_linear.weight, whose
+# 786 k-term sums cancel to 2e-7 --; fp16x2 37 / 11 / 0.  Ceilings = those + 2: the oracle's own fp32 sums depend on the
+# host's thread count and vector width, which moves a tensor across the plain bar now and then.)
+BRANCH_CEILING = {"fp32": (11, 0), "bf16x3": (21, 2), "fp16x2": (13, 1)}
+
+
 @pytest.mark.parametrize("forward_dtype", ["fp32", "bf16x3", "fp16x2"])
 def test_gradients_of_4096_rays_match_oracle_autograd(case, forward_dtype):
     """(bf16x3: forward passes, data-gradient chain and weight-gradient GEMMs on the three-term bf16 kernels; fp16x2: all
-    three on the two-term fp16 kernels, the backward at device-chosen power-of-two scales -- same bars.)"""
+    three on the two-term fp16 kernels, the backward at device-chosen power-of-two scales -- same bars.)
+
+    Random-init weights against uniform-random gt: most gradients here are cancellations of 1.05 M random-signed terms
+    down to ~1e-7, the hardest regime for summation order.  Every tensor must pass ONE of three bars, the test says which
+    one each tensor passed by, and the number of tensors that need the second or third may not grow (BRANCH_CEILING):
+      plain     |hip - ref| <= 2e-4 of the tensor's own max (ref = the oracle's fp32 autograd; tests/test_gpu_backward.py:84);
+      float64   |hip - f64| <= 3 x |ref - f64|: as close to the float64 evaluation as the fp32 reference itself is, times
+                3 (the yardstick of tests/test_gpu_parity.py:39-45) -- for sums whose fp32 summation noise alone is larger
+                than the plain bar (layer 0 sums sin/cos features to ~1e-7);
+      floor     split kernels only: |hip - f64| <= 3e-10 absolute = 3 % of Adam's eps (1e-8), below which no update can
+                change (their rounding is independent of the oracle's, the fp32 kernel's is not).
+    tests below: the same gradients with gt of realistic structure, where the plain bar alone must hold."""
     net, ts, args = _train_step(case, forward_dtype=forward_dtype)
     ts.forward_backward(*args)
     assert abs(float(ts.loss) - case["loss"]) < 1e-5, (float(ts.loss), case["loss"])
     got = _named_flat(ts)
     assert len(got) == 48 and set(got) == set(case["grads"])
-    # Bar per tensor (max norm): within 2e-4 of the tensor's own max of the oracle's fp32 autograd gradient
-    # (tests/test_gpu_backward.py:84), or -- where a gradient is a heavily cancelling sum over 1.05 M points and fp32
-    # summation noise alone exceeds that (layer 0 sums sin/cos features to ~1e-7) -- as close to the float64 evaluation
-    # as the fp32 reference itself is, times 3 (the yardstick of tests/test_gpu_parity.py:39-45).
-    bad, rows = [], []
+    bad, rows, by = [], [], {"plain": [], "float64": [], "floor": []}
     for name, ref in case["grads"].items():
         g, g64 = got[name].cpu(), case["grads64"][name]
         assert torch.isfinite(g).all(), name
         scale = max(float(ref.abs().max()), 1e-30)
         err = float((g - ref).abs().max())
         e_hip64, e_ref64 = float((g - g64).abs().max()), float((ref - g64).abs().max())
-        # ... or, for the bf16x3 forward, whose rounding is independent of the oracle's (the fp32 kernel's is not: same
-        # products, nearly the same order, so its error against the oracle is far below fp32 summation noise), an absolute
-        # floor: 3e-10 = 3 % of Adam's eps (1e-8), below which no update can change.  It is needed by one tensor,
-        # model_fine.alpha_linear.weight, whose 786 k-term sums cancel to 2e-7 (measured error 6.7e-11).
-        ok = err <= 2e-4 * scale or e_hip64 <= 3 * e_ref64 or (forward_dtype != "fp32" and e_hip64 <= 3e-10)
-        rows.append((err / scale, name, scale, e_hip64 / scale, e_ref64 / scale))
-        if not ok:
+        branch = ("plain" if err <= 2e-4 * scale else "float64" if e_hip64 <= 3 * e_ref64 else
+                  "floor" if (forward_dtype != "fp32" and e_hip64 <= 3e-10) else None)
+        rows.append((err / scale, name, scale, e_hip64 / scale, e_ref64 / scale, branch))
+        if branch is None:
             bad.append(rows[-1])
+        else:
+            by[branch].append(name)
         n_ref = float(g64.double().norm())
         assert abs(float(g.double().norm()) - n_ref) <= 2e-3 * max(n_ref, 1e-30), name
     rows.sort(reverse=True)
     for r in rows[:6]:
-        print("grad %-34s |hip-ref|/max %.2e  max %.2e  |hip-f64|/max %.2e  |ref-f64|/max %.2e" % (r[1], r[0], r[2], r[3], r[4]))
+        print("grad %-34s |hip-ref|/max %.2e  max %.2e  |hip-f64|/max %.2e  |ref-f64|/max %.2e  passed by: %s"
+              % (r[1], r[0], r[2], r[3], r[4], r[5]))
+    print(f"{forward_dtype}: bars passed by -- plain {len(by['plain'])}, float64 {len(by['float64'])} {by['float64']}, "
+          f"floor {len(by['floor'])} {by['floor']}")
     assert not bad, bad
+    cap64, cap_floor = BRANCH_CEILING[forward_dtype]
+    assert cap64 is None or len(by["float64"]) <= cap64, by["float64"]
+    assert cap_floor is None or len(by["floor"]) <= cap_floor, by["floor"]
+
+
+@pytest.mark.parametrize("forward_dtype", ["fp32", "bf16x3", "fp16x2"])
+def test_gradients_of_realistic_size_hold_the_plain_bar(case_realistic, forward_dtype):
+    """gt = the oracle's render of a 1 %-perturbed copy of the network: structured residuals, gradients that are not
+    pure cancellation.  Here the plain bar alone -- every one of the 48 tensors within 2e-4 of its own max of the
+    oracle's fp32 autograd gradient -- must hold, for the fp32 kernels and both split routes."""
+    case = case_realistic
+    net, ts, args = _train_step(case, forward_dtype=forward_dtype)
+    ts.forward_backward(*args)
+    assert abs(float(ts.loss) - case["loss"]) < 1e-5 * max(1.0, case["loss"]), (float(ts.loss), case["loss"])
+    got = _named_flat(ts)
+    rows = []
+    for name, ref in case["grads"].items():
+        g = got[name].cpu()
+        assert torch.isfinite(g).all(), name
+        scale = max(float(ref.abs().max()), 1e-30)
+        rows.append((float((g - ref).abs().max()) / scale, name, scale))
+    rows.sort(reverse=True)
+    for r in rows[:6]:
+        print("realistic gt: grad %-34s |hip-ref|/max %.2e  max %.2e" % (r[1], r[0], r[2]))
+    print(f"{forward_dtype}: smallest tensor max {min(r[2] for r in rows):.2e}, largest {max(r[2] for r in rows):.2e}")
+    assert rows[0][0] <= 2e-4, rows[:6]
 
 
 def test_gradient_is_the_mean_of_four_1024_ray_slices(case):
