@@ -236,330 +236,35 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgrad_kernel(WgradJob job) {
     if (tid < M) job.pbias[int64_t(slice) * M + tid] = bsum;
 }
 
-// The same GEMM on the bf16 matrix pipe with three-term operands (split3.h): dW += dY . X^T over a tile's 32 points is two
-// k16-steps of six v_mfma_f32_32x32x16_bf16 per (row block, column block) instead of sixteen v_mfma_f32_32x32x2_f32.
-// Each element is split ONCE per workgroup, on its way from the load registers into LDS, which holds the three bf16
-// planes of both operand tiles ([term][row][32 points], row stride 80 B: a wave's ds_read_b128 of 8 consecutive points
-// per lane is conflict free); a wave then reads ready-made A / B fragments.  Bias gradients (row sums of dY) are summed
-// in fp32 from the load registers (a row is the 8 float4 of 8 neighbouring lanes).
-constexpr int kX3Row = 80;   // bytes per LDS row: 32 bf16 + 16 B pad
-
-template <int NW, int KB>
-__global__ __launch_bounds__(NW * 64, 1) void wgrad_x3_kernel(WgradJob job) {
-    constexpr int NT = NW * 64;
-    constexpr int M = 32 * NW, K = 32 * KB;
-    constexpr int kPlaneA = M * kX3Row, kPlaneB = K * kX3Row;
-    extern __shared__ __attribute__((aligned(16))) char s_x3[];
-    char* sA = s_x3;                   // [3][M][80]
-    char* sB = s_x3 + 3 * kPlaneA;     // [3][K][80]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, kh = lane >> 5;
-    const int slice = blockIdx.x;
-    const int64_t t0 = int64_t(slice) * job.tiles_per_slice;
-    int64_t t1 = t0 + job.tiles_per_slice;
-    if (t1 > job.n_tiles) t1 = job.n_tiles;
-
-    f32x16 acc[KB];
-#pragma unroll
-    for (int a = 0; a < KB; ++a)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
-
-    constexpr int A4 = M * 8, B4 = K * 8;  // float4 pieces per tile (32 floats = 8 float4 per row)
-    constexpr int NA = (A4 + NT - 1) / NT, NB = (B4 + NT - 1) / NT;
-    static_assert(A4 % NT == 0, "every thread holds whole dY pieces (the row sums rely on it)");
-    float4 ra[NA], rb[NB];
-    float bsum[NA];   // lanes with (tid & 7) == 0: row sum of dY row (tid >> 3) + n * NT / 8
-#pragma unroll
-    for (int n = 0; n < NA; ++n) bsum[n] = 0.f;
-
-    auto load_tile = [&](int64_t tile) {
-        const float4* pa = reinterpret_cast<const float4*>(job.a + (tile * job.a_stride + job.a_row0) * 32);
-#pragma unroll
-        for (int n = 0; n < NA; ++n) {
-            const int p = tid + NT * n;
-            ra[n] = (p >> 3) < job.a_rows ? pa[p] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float* xb = job.x + tile * job.x_stride * 32;
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const int p = tid + NT * n;
-            const int row = p >> 3;
-            if (p < B4) {
-                const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
-                rb[n] = reinterpret_cast<const float4*>(xb + src_row * 32)[p & 7];
-            }
-        }
-    };
-    // float4 = 4 consecutive points of a row -> 8 B of each of the row's three bf16 planes
-    auto put = [&](char* plane0, int plane_bytes, int p, const float4& v) {
-        unsigned a0, a1, a2, b0, b1, b2;
-        split_pair(v.x, v.y, a0, a1, a2);
-        split_pair(v.z, v.w, b0, b1, b2);
-        char* d = plane0 + (p >> 3) * kX3Row + (p & 7) * 8;
-        *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
-        *reinterpret_cast<uint2*>(d + plane_bytes) = make_uint2(a1, b1);
-        *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = make_uint2(a2, b2);
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int n = 0; n < NA; ++n) {
-            put(sA, kPlaneA, tid + NT * n, ra[n]);
-            float r = (ra[n].x + ra[n].y) + (ra[n].z + ra[n].w);
-            r += __shfl_xor(r, 1);
-            r += __shfl_xor(r, 2);
-            r += __shfl_xor(r, 4);
-            bsum[n] += r;
-        }
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const int p = tid + NT * n;
-            if (p < B4) put(sB, kPlaneB, p, rb[n]);
-        }
-    };
-
-    if (t0 < t1) load_tile(t0);
-    for (int64_t tile = t0; tile < t1; ++tile) {
-        __syncthreads();  // everyone is done reading the previous tile
-        store_tile();
-        __syncthreads();
-        if (tile + 1 < t1) load_tile(tile + 1);  // in flight under the MFMAs below
-        const char* pa = sA + (wave * 32 + i) * kX3Row + 16 * kh;
-        const char* pb = sB + i * kX3Row + 16 * kh;
-        // 2 k16-steps x KB column blocks = 2 KB groups of six MFMAs.  The fragments of group g + 1 are read under the
-        // MFMAs of group g, one ds_read_b128 per MFMA gap, and every gap is fenced: left alone the compiler sinks each
-        // read to just before its first use and every group then waits out the LDS latency twice (the kernel ran at a
-        // third of the matrix pipe that way).
-        auto frag_a = [&](int s2, int t) { return *reinterpret_cast<const u32x4*>(pa + t * kPlaneA + 32 * s2); };
-        auto frag_b = [&](int g, int t) {
-            return *reinterpret_cast<const u32x4*>(pb + t * kPlaneB + (g % KB) * 32 * kX3Row + 32 * (g / KB));
-        };
-        u32x4 a[2][3], b[2][3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) a[0][t] = frag_a(0, t), b[0][t] = frag_b(0, t);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 2 * KB; ++g) {
-            const int k = g % KB, s2 = g / KB, cur = g & 1;
-            const bool more = g + 1 < 2 * KB;
-            const bool next_a = k == KB - 1 && s2 == 0;          // the other k16-step's A fragments, with the last group
-            u32x4(&A)[3] = a[s2];
-            u32x4(&B)[3] = b[cur];
-#define NRF_WG_GAP(ta, tb, RD)                       \
-    acc[k] = NRF_MFMA_X3(A[ta], B[tb], acc[k]);      \
-    RD;                                              \
-    __builtin_amdgcn_sched_barrier(0);
-            NRF_WG_GAP(2, 0, if (more) b[cur ^ 1][0] = frag_b(g + 1, 0))   // small terms first
-            NRF_WG_GAP(0, 2, if (more) b[cur ^ 1][1] = frag_b(g + 1, 1))
-            NRF_WG_GAP(1, 1, if (more) b[cur ^ 1][2] = frag_b(g + 1, 2))
-            NRF_WG_GAP(1, 0, if (next_a) a[1][0] = frag_a(1, 0))
-            NRF_WG_GAP(0, 1, if (next_a) a[1][1] = frag_a(1, 1))
-            NRF_WG_GAP(0, 0, if (next_a) a[1][2] = frag_a(1, 2))
-#undef NRF_WG_GAP
-        }
-    }
-    float* out = job.partial + int64_t(slice) * M * K;
-#pragma unroll
-    for (int k = 0; k < KB; ++k) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) out[int64_t(wave * 32 + acc_row(t, kh)) * K + k * 32 + i] = acc[k][t];
-    }
-    if ((tid & 7) == 0) {
-#pragma unroll
-        for (int n = 0; n < NA; ++n) job.pbias[int64_t(slice) * M + (tid >> 3) + n * (NT / 8)] = bsum[n];
-    }
-}
-
-// Pipelined form of wgrad_x3_kernel: the tile is processed in two 16-point halves (one k16-step each) through two LDS
-// stages ([stage][term][row][16 points], 48-byte rows: conflict free for the fragments' ds_read_b128), and the split of
-// half sigma + 1 runs in the MFMA gaps of half sigma -- five VALU instructions per gap hide completely under a
-// 32x32x16 MFMA -- instead of in a phase of its own between two barriers, where it and the wait for the global loads
-// cost more than the MFMAs did.  A thread owns the same float4 pieces of every tile (row (tid >> 2) + NT/4 * j, points
-// 16 h + 4 (tid & 3) ..): the registers of half h are refilled from the tile after next as soon as they have been
-// split, one half-step before they are needed again.  One barrier per half.
-constexpr int kX3HalfRow = 48;
-constexpr int kWgradDepth = 3;   // wgrad_h2p_kernel: register sets of loaded halves (2: 4 % slower; 4: spills, 2.5 % slower)
-
-// one third of split_pair (split3.h), so that a pair's 15 instructions spread over three MFMA gaps
-__device__ __forceinline__ void split_phase(float a, float b, int phase, unsigned& p0, unsigned& p1, unsigned& p2, float& r0,
-                                            float& r1) {
-    if (phase == 0) {
-        p0 = pk_bf16(a, b);
-    } else if (phase == 1) {
-        r0 = __fsub_rn(a, bf_lo(p0)), r1 = __fsub_rn(b, bf_hi(p0));
-        p1 = pk_bf16(r0, r1);
-    } else {
-        p2 = pk_bf16(__fsub_rn(r0, bf_lo(p1)), __fsub_rn(r1, bf_hi(p1)));
-    }
-}
-
-template <int NW, int KB>
-__global__ __launch_bounds__(NW * 64, 1) void wgrad_x3p_kernel(WgradJob job) {
-    constexpr int NT = NW * 64;
-    constexpr int M = 32 * NW, K = 32 * KB;
-    constexpr int kPA = M * kX3HalfRow, kPB = K * kX3HalfRow, kStage = 3 * (kPA + kPB);
-    extern __shared__ __attribute__((aligned(16))) char s_x3[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, kh = lane >> 5, q = tid & 3, r0row = tid >> 2;
-    const int slice = blockIdx.x;
-    const int64_t t0 = int64_t(slice) * job.tiles_per_slice;
-    int64_t t1 = t0 + job.tiles_per_slice;
-    if (t1 > job.n_tiles) t1 = job.n_tiles;
-    const int64_t n_half = t1 > t0 ? 2 * (t1 - t0) : 0;   // half-steps of this slice
-
-    f32x16 acc[KB];
-#pragma unroll
-    for (int a = 0; a < KB; ++a)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
-
-    constexpr int NAh = M * 4 / NT;                 // float4 pieces of dY per thread and half: 2
-    constexpr int NBh = (K * 4 + NT - 1) / NT;      // ... of X
-    static_assert(M * 4 % NT == 0 && NAh >= 1, "whole dY pieces per thread");
-    constexpr int NI = NAh + NBh;                   // items per half
-    float4 reg[2][NI];                              // [half][item]: dY items first
-    float bsum[NAh];   // lanes with q == 0: row sum of dY row r0row + (NT / 4) * j
-#pragma unroll
-    for (int n = 0; n < NAh; ++n) bsum[n] = 0.f;
-
-    auto load_half = [&](int64_t hs, float4 (&r)[NI]) {   // hs = half-step index inside the slice
-        const int64_t tile = t0 + (hs >> 1);
-        const int h = int(hs & 1);
-        const float* pa = job.a + (tile * job.a_stride + job.a_row0) * 32 + (4 * h + q) * 4;
-#pragma unroll
-        for (int j = 0; j < NAh; ++j) {
-            const int row = r0row + (NT / 4) * j;
-            r[j] = row < job.a_rows ? *reinterpret_cast<const float4*>(pa + row * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float* xb = job.x + tile * job.x_stride * 32 + (4 * h + q) * 4;
-#pragma unroll
-        for (int j = 0; j < NBh; ++j) {
-            const int row = r0row + (NT / 4) * j;
-            if (row < K) {
-                const int src_row = row < job.x_rows[0] ? job.x_row0[0] + row : job.x_row0[1] + row - job.x_rows[0];
-                r[NAh + j] = *reinterpret_cast<const float4*>(xb + src_row * 32);
-            }
-        }
-    };
-    // sub-slice w of the split of one half (items x 2 pairs x 3 phases); the item's three 8-byte stores ride on its last one
-    unsigned pa0, pa1, pa2, pb0, pb1, pb2;
-    float sr0, sr1;
-    auto split_sub = [&](char* stage, float4 (&r)[NI], int w) {
-        const int item = w / 6, ph = w % 6;
-        const bool is_a = item < NAh;
-        const int row = r0row + (NT / 4) * (is_a ? item : item - NAh);
-        if (!is_a && row >= K) return;
-        const float4 v = r[item];
-        if (ph < 3) split_phase(v.x, v.y, ph, pa0, pa1, pa2, sr0, sr1);
-        else split_phase(v.z, v.w, ph - 3, pb0, pb1, pb2, sr0, sr1);
-        if (ph == 5) {
-            char* d = stage + (is_a ? 0 : 3 * kPA) + row * kX3HalfRow + q * 8;
-            const int plane = is_a ? kPA : kPB;
-            *reinterpret_cast<uint2*>(d) = make_uint2(pa0, pb0);
-            *reinterpret_cast<uint2*>(d + plane) = make_uint2(pa1, pb1);
-            *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2(pa2, pb2);
-            if (is_a) {   // bias gradient: the row's 16 points of this half = the four lanes of a quad
-                float t = (v.x + v.y) + (v.z + v.w);
-                t += nrf_dpp<0xB1>(0.f, t);   // quad_perm [1, 0, 3, 2]
-                t += nrf_dpp<0x4E>(0.f, t);   // quad_perm [2, 3, 0, 1]
-                bsum[item] += t;
-            }
-        }
-    };
-    constexpr int W = NI * 6;          // sub-slices per half
-    constexpr int S = 6 * KB;          // MFMA gaps per half
-
-    // one half-step: MFMAs on stage `cur` (KB groups of six), the split of the next half into the other stage in the gaps
-    auto half_step = [&](const char* cur, char* nxt, float4 (&rn)[NI], bool do_split) {
-        const char* pa = cur + (wave * 32 + i) * kX3HalfRow + 16 * kh;
-        const char* pb = cur + 3 * kPA + i * kX3HalfRow + 16 * kh;
-        auto frag_b = [&](int k, int t) { return *reinterpret_cast<const u32x4*>(pb + t * kPB + k * 32 * kX3HalfRow); };
-        u32x4 a[3], b[2][3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const u32x4*>(pa + t * kPA), b[0][t] = frag_b(0, t);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            const int c = k & 1;
-            const bool more = k + 1 < KB;
-#define NRF_WGP_GAP(m, ta, tb, RD)                                                      \
-    acc[k] = NRF_MFMA_X3(a[ta], b[c][tb], acc[k]);                                      \
-    RD;                                                                                 \
-    if (do_split) {                                                                     \
-        _Pragma("unroll") for (int w = ((k * 6 + m) * W) / S; w < ((k * 6 + m + 1) * W) / S; ++w) split_sub(nxt, rn, w); \
-    }                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);
-            NRF_WGP_GAP(0, 2, 0, if (more) b[c ^ 1][0] = frag_b(k + 1, 0))   // small terms first
-            NRF_WGP_GAP(1, 0, 2, if (more) b[c ^ 1][1] = frag_b(k + 1, 1))
-            NRF_WGP_GAP(2, 1, 1, if (more) b[c ^ 1][2] = frag_b(k + 1, 2))
-            NRF_WGP_GAP(3, 1, 0, (void)0)
-            NRF_WGP_GAP(4, 0, 1, (void)0)
-            NRF_WGP_GAP(5, 0, 0, (void)0)
-#undef NRF_WGP_GAP
-        }
-    };
-
-    if (n_half > 0) {
-        char* st0 = s_x3;
-        char* st1 = s_x3 + kStage;
-        load_half(0, reg[0]);
-        load_half(1, reg[1]);
-#pragma unroll
-        for (int w = 0; w < W; ++w) split_sub(st0, reg[0], w);   // the first half: nothing to hide it under
-        __syncthreads();
-        for (int64_t hs = 0; hs < n_half; hs += 2) {
-            // even half-step: compute stage 0, split half hs + 1 (reg[1]) into stage 1; reg[0] is free: refill it
-            if (hs + 2 < n_half) load_half(hs + 2, reg[0]);
-            half_step(st0, st1, reg[1], true);
-            __syncthreads();
-            // odd half-step: compute stage 1, split half hs + 2 (reg[0]) into stage 0; refill reg[1]
-            const bool more = hs + 2 < n_half;
-            if (hs + 3 < n_half) load_half(hs + 3, reg[1]);
-            half_step(st1, st0, reg[0], more);
-            __syncthreads();
-        }
-    }
-    float* out = job.partial + int64_t(slice) * M * K;
-#pragma unroll
-    for (int k = 0; k < KB; ++k) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) out[int64_t(wave * 32 + acc_row(t, kh)) * K + k * 32 + i] = acc[k][t];
-    }
-    if (q == 0) {
-#pragma unroll
-        for (int n = 0; n < NAh; ++n) job.pbias[int64_t(slice) * M + r0row + (NT / 4) * n] = bsum[n];
-    }
-}
-
-template <int NW, int KB>
-static int launch_wgrad_x3p(const WgradJob& job, unsigned slices, hipStream_t stream) {
-    constexpr int bytes = 2 * 3 * (32 * NW + 32 * KB) * kX3HalfRow;
-    static_assert(bytes <= 160 * 1024, "LDS budget");
-    static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3p_kernel<NW, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                bytes) != hipSuccess)
-            return NRF_ERR_LAUNCH;
-        attr_set[dev] = true;
-    }
-    wgrad_x3p_kernel<NW, KB><<<dim3(slices), NW * 64, bytes, stream>>>(job);
-    return NRF_OK;
-}
-
-// wgrad_x3p_kernel with two fp16 terms per operand (split2h.h) and THREE MFMAs per product into ONE accumulator.  The
+// The weight-gradient GEMM dW += dY . X^T on the bf16 / fp16 matrix pipe with split operands, pipelined: a tile's 32
+// points are processed in two 16-point halves (one k16-step each) through two LDS stages ([stage][plane][row][16 points],
+// 48-byte rows: conflict free for the fragments' ds_read_b128), and the operand split of half s + 1 runs in the MFMA gaps of
+// half s -- a few VALU instructions per gap hide completely under a 32x32x16 MFMA -- instead of in a phase of its own
+// between two barriers.  A thread owns the same float4 pieces of every tile (row (tid >> 2) + NT/4 * j, points
+// 16 h + 4 (tid & 3) ..).  One barrier per half.  Bias gradients (row sums of dY) are summed in fp32 from the load registers.
+//
+// X3 (wgrad_x3p_kernel, the route that carries the reference's 24-bit operands): three bf16 terms per operand
+// (split3.h), six v_mfma_f32_32x32x16_bf16 per product block, planes [dY 0 | 1 | 2 | X 0 | 1 | 2].
+//
+// !X3 (wgrad_h2p_kernel): two fp16 terms per operand (split2h.h) and THREE MFMAs per product into ONE accumulator.  The
 // second accumulator of the forward kernels would cost KB more blocks here; instead the dY operand, whose scale is ours
 // to choose, is multiplied by 2^T so that its row set's largest entry (left by mlp_dgrad_h2_kernel in the chain's scale
 // block) lands in [2048, 4096), and its planes are hi, hi * 2^-11 and the UNSCALED low term: a_hi.b_hi, (a_hi 2^-11).b_lo'
 // and a_lo.b_hi then share one scale.  The two small planes go subnormal for entries below 2^-15 of the maximum, whose
 // absolute error (2^-25 of the scaled operand) is 2^-37 of the largest term; X keeps the forward's hi | lo * 2^11.  The
-// sums are unscaled (exactly) when the partials are written.  LDS: [stage][dY hi | hs | lo | X hi | lo'][row][16 points].
-template <int NW, int KB>
-__global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
+// sums are unscaled (exactly) when the partials are written.  Planes [dY hi | hs | lo | X hi | lo'].
+//
+// Both forms share the loader: operand halves are requested kWgradDepth - 1 half-steps ahead by inline-asm loads and
+// waited for by counted s_waitcnt (round 2 built this for the fp16 form; round 3 gave the bf16x3 form the same loader --
+// it had run on compiler-placed vmcnt(0) waits, i.e. without any prefetch).
+constexpr int kX3HalfRow = 48;
+constexpr int kWgradDepth = 3;   // register sets of loaded halves (2: 4 % slower; 4: spills, 2.5 % slower)
+
+template <int NW, int KB, bool X3>
+__device__ __forceinline__ void wgrad_p_body(const WgradJob& job) {
     constexpr int NT = NW * 64;
     constexpr int M = 32 * NW, K = 32 * KB;
-    constexpr int kPA = M * kX3HalfRow, kPB = K * kX3HalfRow, kStage = 3 * kPA + 2 * kPB;
+    constexpr int kPA = M * kX3HalfRow, kPB = K * kX3HalfRow, kStage = 3 * kPA + (X3 ? 3 : 2) * kPB;
     extern __shared__ __attribute__((aligned(16))) char s_x3[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5, q = tid & 3, r0row = tid >> 2;
@@ -570,7 +275,7 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
     const int64_t n_half = t1 > t0 ? 2 * (t1 - t0) : 0;   // half-steps of this slice
     // stored dY = chain value * 2^-S; chain maximum of the row set in scale_words[scale_word]
     int T = 0;
-    {
+    if constexpr (!X3) {
         const unsigned row_max = job.scale_words[job.scale_word];
         if (((row_max >> 23) & 0xffu) != 0)
             T = scale_exponent(job.scale_words[0], kChainScaleTarget) + scale_exponent(row_max, kWgradScaleTarget);
@@ -618,7 +323,7 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
     // those lanes load the last live row and store nothing (split_sub)
     const unsigned voff = unsigned(r0row * 32 + q * 4) * 4u;
     unsigned voff_last = voff;
-    {
+    if constexpr ((NT / 4) * NBh > K) {   // (no tail when the groups tile K exactly: one register less in the 256 x 256 kernel)
         const int row = r0row + (NT / 4) * (NBh - 1);
         if (row >= K) voff_last = unsigned((K - 1 - (NT / 4) * (NBh - 1)) * 32 + q * 4) * 4u;
     }
@@ -660,7 +365,16 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
     unsigned p1[3], p2[3];   // the planes' words of the item's first / second pair
     float sx, sy, r0, r1;
     auto pair_phase = [&](bool is_a, float x, float y, int phase, unsigned (&p)[3]) {
-        if (phase == 0) {
+        if constexpr (X3) {   // one third of split_pair (split3.h): a pair's 15 instructions spread over three sub-slices
+            if (phase == 0) {
+                p[0] = pk_bf16(x, y);
+            } else if (phase == 1) {
+                r0 = __fsub_rn(x, bf_lo(p[0])), r1 = __fsub_rn(y, bf_hi(p[0]));
+                p[1] = pk_bf16(r0, r1);
+            } else {
+                p[2] = pk_bf16(__fsub_rn(r0, bf_lo(p[1])), __fsub_rn(r1, bf_hi(p[1])));
+            }
+        } else if (phase == 0) {
             sx = is_a ? x * sc : x, sy = is_a ? y * sc : y;
             p[0] = pk_f16(sx, sy);
         } else if (phase == 1) {
@@ -680,15 +394,30 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
         const int row = r0row + (NT / 4) * (is_a ? item : item - NAh);
         if (!is_a && row >= K) return;
         const f32x4v v = r[item];
-        if (ph < 3) pair_phase(is_a, v.x, v.y, ph, p1);
-        else pair_phase(is_a, v.z, v.w, ph - 3, p2);
+        char* d = stage + (is_a ? 0 : 3 * kPA) + row * kX3HalfRow + q * 8;
+        const int plane = is_a ? kPA : kPB;
+        if constexpr (X3) {
+            // each pair's three plane words are stored as soon as the pair is split (4-byte stores): one set of plane
+            // words live instead of two -- the three registers the 256 x 256 kernel did not have
+            if (ph < 3) pair_phase(is_a, v.x, v.y, ph, p1);
+            else pair_phase(is_a, v.z, v.w, ph - 3, p1);
+            if (ph == 2 || ph == 5) {
+                char* dp = d + (ph == 5 ? 4 : 0);
+                *reinterpret_cast<unsigned*>(dp) = p1[0];
+                *reinterpret_cast<unsigned*>(dp + plane) = p1[1];
+                *reinterpret_cast<unsigned*>(dp + 2 * plane) = p1[2];
+            }
+        } else {
+            if (ph < 3) pair_phase(is_a, v.x, v.y, ph, p1);
+            else pair_phase(is_a, v.z, v.w, ph - 3, p2);
+        }
         if (ph == 5) {
-            char* d = stage + (is_a ? 0 : 3 * kPA) + row * kX3HalfRow + q * 8;
-            const int plane = is_a ? kPA : kPB;
-            *reinterpret_cast<uint2*>(d) = make_uint2(p1[0], p2[0]);
-            *reinterpret_cast<uint2*>(d + plane) = make_uint2(p1[1], p2[1]);
+            if constexpr (!X3) {
+                *reinterpret_cast<uint2*>(d) = make_uint2(p1[0], p2[0]);
+                *reinterpret_cast<uint2*>(d + plane) = make_uint2(p1[1], p2[1]);
+                if (is_a) *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2(p1[2], p2[2]);
+            }
             if (is_a) {
-                *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2(p1[2], p2[2]);
                 // bias gradient: the row's 16 points of this half = the four lanes of a quad
                 float t = (v.x + v.y) + (v.z + v.w);
                 t += nrf_dpp<0xB1>(0.f, t);   // quad_perm [1, 0, 3, 2]
@@ -710,34 +439,48 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+a"(reg[d][0]), "+a"(reg[d][1]), "+a"(reg[d][2]), "+a"(reg[d][3]), "+a"(reg[d][4]),
                              "+a"(reg[d][5]), "+a"(reg[d][6]) : : "memory");
     };
-    constexpr int W = NI * 6;          // sub-slices per half
-    constexpr int S = 3 * KB;          // MFMA gaps per half
+    constexpr int W = NI * 6;                    // sub-slices per half
+    constexpr int G = X3 ? 6 : 3;                // MFMAs (= gaps) per column block
+    constexpr int S = G * KB;                    // MFMA gaps per half
 
-    // one half-step: MFMAs on stage `cur` (KB groups of three), the split of the next half into the other stage in the gaps
+    // one half-step: MFMAs on stage `cur` (KB groups of G), the split of the next half into the other stage in the gaps
     auto half_step = [&](const char* cur, char* nxt, f32x4v (&rn)[NI], bool do_split) {
         const char* pa = cur + (wave * 32 + i) * kX3HalfRow + 16 * kh;
         const char* pb = cur + 3 * kPA + i * kX3HalfRow + 16 * kh;
         auto frag_b = [&](int k, int t) { return *reinterpret_cast<const u32x4*>(pb + t * kPB + k * 32 * kX3HalfRow); };
-        u32x4 a[3], b[2][2];
+        // fp16 form: both B planes double-buffered over the column blocks.  bf16x3 form: only plane 0, which the block's
+        // first and last products read; planes 1 and 2 are dead after the block's gaps 3 and 0, so the next block's
+        // fragments land in the same registers (24 -> 16 fragment registers: the 256 x 256 kernel spilled without it).
+        u32x4 a[3], b[2][2], b2x;
 #pragma unroll
         for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const u32x4*>(pa + t * kPA);
         b[0][0] = frag_b(0, 0), b[0][1] = frag_b(0, 1);
+        if constexpr (X3) b2x = frag_b(0, 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
             const int c = k & 1;
             const bool more = k + 1 < KB;
-#define NRF_WGH_GAP(m, ta, tb, RD)                                                      \
-    acc[k] = NRF_MFMA_F16(a[ta], b[c][tb], acc[k]);                                     \
+#define NRF_WGP_GAP(MFMA, m, A, B, RD)                                                  \
+    acc[k] = MFMA(A, B, acc[k]);                                                        \
     RD;                                                                                 \
     if (do_split) {                                                                     \
-        _Pragma("unroll") for (int w = ((k * 3 + m) * W) / S; w < ((k * 3 + m + 1) * W) / S; ++w) split_sub(nxt, rn, w); \
+        _Pragma("unroll") for (int w = ((k * G + m) * W) / S; w < ((k * G + m + 1) * W) / S; ++w) split_sub(nxt, rn, w); \
     }                                                                                   \
     __builtin_amdgcn_sched_barrier(0);
-            NRF_WGH_GAP(0, 2, 0, if (more) b[c ^ 1][0] = frag_b(k + 1, 0))   // small terms first: a_lo . b_hi
-            NRF_WGH_GAP(1, 1, 1, if (more) b[c ^ 1][1] = frag_b(k + 1, 1))   // (a_hi 2^-11) . b_lo'
-            NRF_WGH_GAP(2, 0, 0, (void)0)                                    // a_hi . b_hi
-#undef NRF_WGH_GAP
+            if constexpr (X3) {   // six products with i + j <= 2, small terms first (split3.h); plane 1 lives in b[0][1]
+                NRF_WGP_GAP(NRF_MFMA_X3, 0, a[0], b2x, if (more) b[c ^ 1][0] = frag_b(k + 1, 0))
+                NRF_WGP_GAP(NRF_MFMA_X3, 1, a[2], b[c][0], if (more) b2x = frag_b(k + 1, 2))
+                NRF_WGP_GAP(NRF_MFMA_X3, 2, a[1], b[0][1], (void)0)
+                NRF_WGP_GAP(NRF_MFMA_X3, 3, a[0], b[0][1], (void)0)
+                NRF_WGP_GAP(NRF_MFMA_X3, 4, a[1], b[c][0], if (more) b[0][1] = frag_b(k + 1, 1))
+                NRF_WGP_GAP(NRF_MFMA_X3, 5, a[0], b[c][0], (void)0)
+            } else {
+                NRF_WGP_GAP(NRF_MFMA_F16, 0, a[2], b[c][0], if (more) b[c ^ 1][0] = frag_b(k + 1, 0))   // small terms first: a_lo . b_hi
+                NRF_WGP_GAP(NRF_MFMA_F16, 1, a[1], b[c][1], if (more) b[c ^ 1][1] = frag_b(k + 1, 1))   // (a_hi 2^-11) . b_lo'
+                NRF_WGP_GAP(NRF_MFMA_F16, 2, a[0], b[c][0], (void)0)                                    // a_hi . b_hi
+            }
+#undef NRF_WGP_GAP
         }
     };
 
@@ -815,12 +558,38 @@ __global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) {
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) out[int64_t(wave * 32 + acc_row(t, kh)) * K + k * 32 + i] = acc[k][t] * unsc;
+        for (int t = 0; t < 16; ++t) out[int64_t(wave * 32 + acc_row(t, kh)) * K + k * 32 + i] = X3 ? acc[k][t] : acc[k][t] * unsc;
     }
     if (q == 0) {
 #pragma unroll
         for (int n = 0; n < NAh; ++n) job.pbias[int64_t(slice) * M + r0row + (NT / 4) * n] = bsum[n];
     }
+}
+
+template <int NW, int KB>
+__global__ __launch_bounds__(NW * 64, 1) void wgrad_h2p_kernel(WgradJob job) { wgrad_p_body<NW, KB, false>(job); }
+
+template <int NW, int KB>
+__global__ __launch_bounds__(NW * 64, 1) void wgrad_x3p_kernel(WgradJob job) { wgrad_p_body<NW, KB, true>(job); }
+
+template <int NW, int KB>
+static int launch_wgrad_x3p(const WgradJob& job, unsigned slices, hipStream_t stream) {
+    constexpr int bytes = 2 * 3 * (32 * NW + 32 * KB) * kX3HalfRow;
+    static_assert(bytes <= 160 * 1024, "LDS budget");
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3p_kernel<NW, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                bytes) != hipSuccess)
+            return NRF_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
+    if (job.a_rows != 32 * NW) return NRF_ERR_SHAPE;   // the kernel's dY loads are unconditional
+    // ... and a group of NW * 16 X rows lies in one segment (the clamped tail of the last group aside)
+    if (job.x_rows[0] < 32 * KB && job.x_rows[0] % (NW * 16) != 0) return NRF_ERR_SHAPE;
+    wgrad_x3p_kernel<NW, KB><<<dim3(slices), NW * 64, bytes, stream>>>(job);
+    return NRF_OK;
 }
 
 template <int NW, int KB>
@@ -843,24 +612,6 @@ static int launch_wgrad_h2p(const WgradJob& job, unsigned slices, hipStream_t st
     return NRF_OK;
 }
 
-template <int NW, int KB>
-static int launch_wgrad_x3(const WgradJob& job, unsigned slices, hipStream_t stream) {
-    constexpr int bytes = 3 * (32 * NW + 32 * KB) * kX3Row;
-    static_assert(bytes <= 160 * 1024, "LDS budget");
-    static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_x3_kernel<NW, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                bytes) != hipSuccess)
-            return NRF_ERR_LAUNCH;
-        attr_set[dev] = true;
-    }
-    wgrad_x3_kernel<NW, KB><<<dim3(slices), NW * 64, bytes, stream>>>(job);
-    return NRF_OK;
-}
-
-// Column c of a wgrad job's K axis -> column of the reference weight matrix (or -1: padding).
 struct ColMap {
     int seg_cols[2];   // columns of each X segment
     int seg_kind[2];   // 0: hidden (identity), L > 0: encoding with L frequencies in kernel slot order
@@ -1082,8 +833,14 @@ static int mlp_backward_impl(const float* packed, const float* packed_t, const v
                 reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 5);
                 continue;
             }
-            if (x3) { if (const int rc = launch_wgrad_x3<8, 10>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256), slices, stream)) return rc; }
-            else wgrad_kernel<8, 10, false><<<grid, 512, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
+            if (x3) {   // the same two GEMMs on the three-term kernel
+                if (const int rc = launch_wgrad_x3p<8, 8>(job(5 * 256, 256, kActH + 4 * 256, 256, 0, 0), slices, stream)) return rc;
+                reduce(256, 256, 256, ColMap{{256, 0}, {0, 0}, {63, 0}}, 5);
+                if (const int rc = launch_wgrad_x3p<8, 2>(job(5 * 256, 256, kActPe, 64, 0, 0), slices, stream)) return rc;
+                reduce(256, 64, 256, ColMap{{64, 0}, {10, 0}, {0, 0}}, 5);
+                continue;
+            }
+            wgrad_kernel<8, 10, false><<<grid, 512, 0, stream>>>(job(5 * 256, 256, kActPe, 64, kActH + 4 * 256, 256));
             reduce(256, 320, 256, ColMap{{64, 256}, {10, 0}, {0, 63}}, 5);
         } else {
             if (h2) { if (const int rc = launch_wgrad_h2p<8, 8>(job(l * 256, 256, kActH + (l - 1) * 256, 256, 0, 0, kGmaxLayer0 + l), slices, stream)) return rc; }

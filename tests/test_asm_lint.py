@@ -6,7 +6,8 @@ mlp_fp16x2_kernel and mlp_dgrad_h2_kernel (nerf_amd/csrc/mlp_fp16x2.hip) load a 
 puts a copy of such a register between the load and its wait, the copy reads the old contents and the results are
 wrong only sometimes.  This test reads the gfx950 code objects out of the built library and checks, in program order,
 that no instruction names a register while a load into it may still be in flight (an in-order model of vmcnt over
-each kernel's control-flow graph).  wgrad_h2p_kernel (mlp_bwd.hip) loads its operand sets the same way.
+each kernel's control-flow graph).  wgrad_h2p_kernel and wgrad_x3p_kernel (mlp_bwd.hip: one loader, wgrad_p_body) load their
+operand sets the same way.
 """
 import os
 import re
@@ -192,5 +193,5 @@ def test_prefetched_registers_are_not_touched_before_their_wait(tmp_path):
         total += n
         kernels.update(re.findall(r"^[0-9a-f]+ <(.+)>:$", out, re.M))
     assert total > 500, total
-    for k in ("mlp_fp16x2_kernel", "mlp_dgrad_h2_kernel", "wgrad_h2p_kernel"):   # the kernels with asm loads
+    for k in ("mlp_fp16x2_kernel", "mlp_dgrad_h2_kernel", "wgrad_h2p_kernel", "wgrad_x3p_kernel"):   # the kernels with asm loads
         assert any(k in name for name in kernels), k
