@@ -92,6 +92,9 @@ def parse(argv=None):
                          "the bf16 MLP of configs[4], reported under its own metric name.  --mode train runs its matrix work "
                          "on the kernels of the same --dtype (bf16x3, fp32 or fp16x2); --mode kilo runs the tiny MLPs on the "
                          "fp32 MFMA kernel unless --dtype fp16x2")
+    ap.add_argument("--kilo-dirs", default="per_ray", choices=["per_ray", "per_point"],
+                    help="kilo mode: direction encodings once per ray from a table (default) or re-evaluated per point as the "
+                         "reference does (A/B switch; bit-identical outputs)")
     ap.add_argument("--train-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -379,7 +382,8 @@ def kilo_bench(args, dev, rank, world, dist):
         e0 = E()
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(rays_o, rays_d, r.occ_grid, aabb, r.near, r.far, r.step)
         e1 = E()
-        raw = kilo_ops.kilo_forward(packed, net.num_models, aabb, res, pts, rays_d, ray_idx, kind=kind)
+        raw = kilo_ops.kilo_forward(packed, net.num_models, aabb, res, pts, rays_d, ray_idx, kind=kind,
+                                    encode_dirs_per_ray=getattr(args, "kilo_dirs", "per_ray") == "per_ray")
         e2 = E()
         out = kilo_ops.kilo_composite(raw, ts, te, offsets, counts, r.ert, True)
         e3 = E()

@@ -289,6 +289,20 @@ int nrf_kilo_forward_fp16x2(const float* packed_h2, int num_cells, const float* 
                             const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points, float* raw,
                             void* workspace, int64_t workspace_bytes, nrf_stream_t stream);
 
+/* Network.forward with the direction encodings evaluated once per RAY instead of once per point.  The reference expands
+ * viewdirs per point and embeds every copy (network.py:243, 276-283); the 27 direction features depend on the ray only.
+ * nrf_kilo_encode_dirs writes, per row of dirs (n_dirs, 3), the view layer's direction operands exactly as the kernels'
+ * lanes would compute them (fp16x2 != 0: as the two-term fp16 fragments of nrf_kilo_forward_fp16x2, plus the range
+ * guard's maximum per row) into `table` (nrf_kilo_dir_table_bytes(n_dirs) bytes, 16-byte aligned, 132 B per row);
+ * nrf_kilo_forward_encoded is nrf_kilo_forward / nrf_kilo_forward_fp16x2 (fp16x2 selects; `packed` accordingly) reading
+ * that table through dir_index (required) -- bit-identical raw, ~100 fewer VALU instructions per 32-point tile.
+ * n_dirs <= 2^24. */
+int64_t nrf_kilo_dir_table_bytes(int64_t n_dirs);
+int nrf_kilo_encode_dirs(const float* dirs, int64_t n_dirs, int fp16x2, void* table, nrf_stream_t stream);
+int nrf_kilo_forward_encoded(const float* packed, int fp16x2, int num_cells, const float* aabb_host, const int* res_host,
+                             const float* pts, const void* dir_table, int64_t n_dirs, const int32_t* dir_index,
+                             int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream);
+
 /* nrf_kilo_pack_weights (and, with packed_t non-NULL, nrf_kilo_pack_weights_transposed) for the cells with
  * cell_mask[cell] != 0 only (int32 per cell, device); the other cells' records are left as they are. */
 int nrf_kilo_pack_weights_cells(const float* const* tensors_host, int num_cells, const int32_t* cell_mask, float* packed,

@@ -215,6 +215,59 @@ __global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict
     }
 }
 
+// ---- direction encodings once per RAY (nrf_kilo_encode_dirs) --------------------------------------------------------
+// The 27 direction features (network.py:243: viewdirs expanded per point, then embedded per point) depend on the ray
+// only, and a ray puts ~25 consecutive samples into a cell: evaluated per point they were 3 of the 11 trig iterations
+// of a tile (~100 of its ~540 VALU instructions, plus an operand split in the fp16 form).  The table holds, per
+// direction row, exactly what the kernels' lanes would have computed: 2 lane halves x 16 dwords = 128 B --
+//   fp32 form:   the 16 slots of encode_pe_doubling<4> (the B operands of the view layer's last k-block);
+//   fp16x2 form: split_block_f16 of those slots, [k16-step][term][4 dwords], and behind the table one float per row,
+//                the range guard's maximum of the row's operands;
+// produced by the same device functions, so a table-fed tile is bit-identical to a self-encoding one.  A tile loads its
+// 64 B per lane at its top (four global_load_dwordx4; neighbouring points share rays, so the rows come from L1 / L2) and
+// uses them three layers later.
+constexpr int kDirRowDwords = 32;
+__attribute__((unused)) inline int64_t dir_table_bytes(int64_t n_dirs) { return a256(n_dirs * kDirRowDwords * 4) + a256(n_dirs * 4); }
+
+template <bool H2>
+__global__ __launch_bounds__(256) void kilo_dir_table_kernel(const float* __restrict__ dirs, int64_t n_dirs,
+                                                             unsigned* __restrict__ table, float* __restrict__ guard) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32 + j;
+    const int64_t src = row < n_dirs ? row : n_dirs - 1;   // every lane runs (the encoding swaps between lane halves)
+    f32x16 e[1];
+    encode_pe_doubling<4>(dirs[src * 3], dirs[src * 3 + 1], dirs[src * 3 + 2], h, e);
+    u32x4 out[4];
+    if (H2) {
+        float ovf = 0.f;
+        u32x4 f[2][2];
+        split_block_f16(e[0], f, ovf);
+        out[0] = f[0][0], out[1] = f[0][1], out[2] = f[1][0], out[3] = f[1][1];
+        ovf = fmaxf(ovf, __shfl_xor(ovf, 32));
+        if (row < n_dirs && h == 0) guard[row] = ovf;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[q][c] = __float_as_uint(e[0][4 * q + c]);
+    }
+    if (row < n_dirs) {
+        u32x4* dst = reinterpret_cast<u32x4*>(table + (row * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = out[q];
+    }
+}
+
+// heads: dot products over the 16 registers of a block, two terms per v_pk_fma_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot16(const f32x16& w, const f32x16& x) {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) acc = __builtin_elementwise_fma((f32x2){w[t], w[t + 1]}, (f32x2){x[t], x[t + 1]}, acc);
+    return acc[0] + acc[1];
+}
+
 // Persistent waves over jobs; job = up to kJobTiles 32-point tiles of one cell's sorted segment.
 //
 // What bounds it (measured): on gfx950 the f32 MFMA runs at the vector-ALU rate (64 cycles per
@@ -228,7 +281,8 @@ __global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict
 // instruction mix (837 tiles per SIMD x (96 x 64 + 540 x 4) cycles = 3.3 ms at 2.1 GHz): f32 MFMA and VALU share
 // the SIMD's issue cycles, so more waves do not help -- a workgroup-shared LDS copy of the whole cell record with
 // four waves per SIMD (112 registers) measured 3.5 ms.  Only fewer instructions per tile would.
-template <bool INDEXED>  // directions gathered through dir_index (one per ray) or given per point
+template <bool INDEXED, bool TABLE>  // directions gathered through dir_index (one per ray) or given per point; TABLE:
+                                     // `dirs` is the per-ray encoding table of kilo_dir_table_kernel<false> (INDEXED only)
 __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
                                                           const int* __restrict__ seg_start,
                                                           const int* __restrict__ job_prefix,
@@ -276,12 +330,14 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
         auto tile_id = [&](int t0) { const int k = t0 + j; return unsigned(perm[unsigned(k < last ? k : last)]); };
         auto dir_of = [&](unsigned id) { return INDEXED ? unsigned(dir_index[id]) : id; };  // no branch in the tile loop
         unsigned id_c = tile_id(first), id_n = tile_id(first + 32), id_nn = tile_id(first + 64);
-        float pc[3], pn[3], dc[3];
-        unsigned di_n;
+        float pc[3], pn[3], dc[3] = {0.f, 0.f, 0.f};
+        unsigned di_n, di_c = dir_of(id_c);   // (di_c: the current tile's table row, TABLE only)
         {
-            const unsigned di_c = dir_of(id_c);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) pc[a] = pts[id_c * 3u + a], dc[a] = dirs[di_c * 3u + a];
+            for (int a = 0; a < 3; ++a) {
+                pc[a] = pts[id_c * 3u + a];
+                if (!TABLE) dc[a] = dirs[di_c * 3u + a];
+            }
 #pragma unroll
             for (int a = 0; a < 3; ++a) pn[a] = pts[id_n * 3u + a];
             di_n = dir_of(id_n);
@@ -290,17 +346,28 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
             const bool valid = t0 + j < seg_e;
             const unsigned id = id_c;
             const float px = pc[0], py = pc[1], pz = pc[2], dx = dc[0], dy = dc[1], dz = dc[2];
-            {   // issue the loads of the following tiles, rotate the pipeline registers
-                float dn[3], pnn[3];
+            f32x16 x[2], xd;
+            if (TABLE) {   // this tile's direction block: the table row of its ray, this lane half's 64 B (used three layers on)
+                const float4* row = reinterpret_cast<const float4*>(dirs) + (size_t(di_c) * 2u + unsigned(h)) * 4u;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) dn[a] = dirs[di_n * 3u + a], pnn[a] = pts[id_nn * 3u + a];
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = row[q];
+                    xd[4 * q] = v.x, xd[4 * q + 1] = v.y, xd[4 * q + 2] = v.z, xd[4 * q + 3] = v.w;
+                }
+            }
+            {   // issue the loads of the following tiles, rotate the pipeline registers
+                float dn[3] = {0.f, 0.f, 0.f}, pnn[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    if (!TABLE) dn[a] = dirs[di_n * 3u + a];
+                    pnn[a] = pts[id_nn * 3u + a];
+                }
                 const unsigned di_nn = dir_of(id_nn);
                 const unsigned id_nnn = tile_id(t0 + 96);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) pc[a] = pn[a], dc[a] = dn[a], pn[a] = pnn[a];
-                id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_n = di_nn;
+                id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_c = di_n, di_n = di_nn;
             }
-            f32x16 x[2];
             encode_pe_doubling<10>(px, py, pz, h, x);
             // a run-time zero the compiler cannot see through: the LDS reads below are loop-invariant, and LICM
             // would hoist all of them back into 128 registers held across the tile loop
@@ -310,26 +377,14 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
             const float* sm = sm_job + again;
             x[0] = relu16(tiny_layer<2>(w, lds16(bias_h), x));              // pts_linears 0 (network.py:132-138)
             x[0] = relu16(tiny_layer<1>(w + 8, lds16(bias_h + 32), x));     // pts_linears 1
-            float sigma = 0.f;                                              // sigma_linear (:142-144)
-            {
-                const f32x16 sw = lds16(sm + kKOffSigW + h * 16);
-#pragma unroll
-                for (int t = 0; t < 16; ++t) sigma = fmaf(sw[t], x[0][t], sigma);
-            }
+            float sigma = dot16(lds16(sm + kKOffSigW + h * 16), x[0]);      // sigma_linear (:142-144)
             x[0] = tiny_layer<1>(w + 12, lds16(bias_h + 64), x);            // feature_linear (:147-149), no activation
-            encode_pe_doubling<4>(dx, dy, dz, h, x + 1);
+            if (TABLE) x[1] = xd;
+            else encode_pe_doubling<4>(dx, dy, dz, h, x + 1);
             const f32x16 hv = relu16(tiny_layer<2>(w + 16, lds16(bias_h + 96), x));  // view_linears on cat([feature, dirs]) (:152-156)
-            float r = 0.f, g = 0.f, b = 0.f;                                // rgb_linear (:159-161)
-            {
-                const f32x16 r0 = lds16(sm + kKOffRgbW + h * 16), r1 = lds16(sm + kKOffRgbW + 32 + h * 16),
-                             r2 = lds16(sm + kKOffRgbW + 64 + h * 16);
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    r = fmaf(r0[t], hv[t], r);
-                    g = fmaf(r1[t], hv[t], g);
-                    b = fmaf(r2[t], hv[t], b);
-                }
-            }
+            // rgb_linear (:159-161)
+            float r = dot16(lds16(sm + kKOffRgbW + h * 16), hv), g = dot16(lds16(sm + kKOffRgbW + 32 + h * 16), hv),
+                  b = dot16(lds16(sm + kKOffRgbW + 64 + h * 16), hv);
             r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
             if (h == 0 && valid) raw[id] = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
         }
@@ -429,13 +484,14 @@ __device__ __forceinline__ f32x16 tiny_layer_h2(const u32x4 (*w)[2], f32x16 init
 
 // kilo_mlp_kernel with the cell's matrices as fp16x2 fragments (96 registers, as before).  Points whose operands leave
 // fp16's range, and every point of a cell with such a weight, come out as NaN (mlp_fp16x2.hip's guard).
-template <bool INDEXED>
+template <bool INDEXED, bool TABLE>   // TABLE: `dirs` is the table of kilo_dir_table_kernel<true>, `dir_guard` its range-guard column
 __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
                                                              const int* __restrict__ seg_start,
                                                              const int* __restrict__ job_prefix,
                                                              const int* __restrict__ perm, const float* __restrict__ pts,
                                                              const float* __restrict__ dirs,
-                                                             const int* __restrict__ dir_index, float4* __restrict__ raw) {
+                                                             const int* __restrict__ dir_index, float4* __restrict__ raw,
+                                                             const float* __restrict__ dir_guard) {
     __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
@@ -474,12 +530,14 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
         auto tile_id = [&](int t0) { const int k = t0 + j; return unsigned(perm[unsigned(k < last ? k : last)]); };
         auto dir_of = [&](unsigned id) { return INDEXED ? unsigned(dir_index[id]) : id; };
         unsigned id_c = tile_id(first), id_n = tile_id(first + 32), id_nn = tile_id(first + 64);
-        float pc[3], pn[3], dc[3];
-        unsigned di_n;
+        float pc[3], pn[3], dc[3] = {0.f, 0.f, 0.f};
+        unsigned di_n, di_c = dir_of(id_c);   // (di_c: the current tile's table row, TABLE only)
         {
-            const unsigned di_c = dir_of(id_c);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) pc[a] = pts[id_c * 3u + a], dc[a] = dirs[di_c * 3u + a];
+            for (int a = 0; a < 3; ++a) {
+                pc[a] = pts[id_c * 3u + a];
+                if (!TABLE) dc[a] = dirs[di_c * 3u + a];
+            }
 #pragma unroll
             for (int a = 0; a < 3; ++a) pn[a] = pts[id_n * 3u + a];
             di_n = dir_of(id_n);
@@ -488,19 +546,27 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
             const bool valid = t0 + j < seg_e;
             const unsigned id = id_c;
             const float px = pc[0], py = pc[1], pz = pc[2], dx = dc[0], dy = dc[1], dz = dc[2];
+            float ovf = poison, dguard = 0.f;
+            f32x16 e[2];
+            u32x4 xpe[2][2][2], xh[1][2][2], xv[2][2][2];
+            if (TABLE) {   // this tile's direction fragments: the table row of its ray, this lane half's 64 B
+                const u32x4* row = reinterpret_cast<const u32x4*>(dirs) + (size_t(di_c) * 2u + unsigned(h)) * 4u;
+                xv[1][0][0] = row[0], xv[1][0][1] = row[1], xv[1][1][0] = row[2], xv[1][1][1] = row[3];
+                dguard = dir_guard[di_c];   // folded into ovf at the tile's end: a use up here makes the compiler wait for it --
+            }                               // the newest load, so vmcnt(0) -- right behind the row loads, every tile
             {
-                float dn[3], pnn[3];
+                float dn[3] = {0.f, 0.f, 0.f}, pnn[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) dn[a] = dirs[di_n * 3u + a], pnn[a] = pts[id_nn * 3u + a];
+                for (int a = 0; a < 3; ++a) {
+                    if (!TABLE) dn[a] = dirs[di_n * 3u + a];
+                    pnn[a] = pts[id_nn * 3u + a];
+                }
                 const unsigned di_nn = dir_of(id_nn);
                 const unsigned id_nnn = tile_id(t0 + 96);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) pc[a] = pn[a], dc[a] = dn[a], pn[a] = pnn[a];
-                id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_n = di_nn;
+                id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_c = di_n, di_n = di_nn;
             }
-            float ovf = poison;
-            f32x16 e[2];
-            u32x4 xpe[2][2][2], xh[1][2][2], xv[2][2][2];
             encode_pe_doubling<10>(px, py, pz, h, e);
             split_block_f16(e[0], xpe[0], ovf);
             split_block_f16(e[1], xpe[1], ovf);
@@ -511,31 +577,20 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
             f32x16 y = relu16(tiny_layer_h2<2>(w, lds16(bias_h), xpe));             // pts_linears 0 (network.py:132-138)
             split_block_f16(y, xh[0], ovf);
             y = relu16(tiny_layer_h2<1>(w + 4, lds16(bias_h + 32), xh));            // pts_linears 1
-            float sigma = 0.f;                                                      // sigma_linear (:142-144)
-            {
-                const f32x16 sw = lds16(sm + kKOffSigW + h * 16);
-#pragma unroll
-                for (int t = 0; t < 16; ++t) sigma = fmaf(sw[t], y[t], sigma);
-            }
+            float sigma = dot16(lds16(sm + kKOffSigW + h * 16), y);                 // sigma_linear (:142-144)
             split_block_f16(y, xh[0], ovf);
             y = tiny_layer_h2<1>(w + 6, lds16(bias_h + 64), xh);                    // feature_linear (:147-149), no activation
             split_block_f16(y, xv[0], ovf);
-            encode_pe_doubling<4>(dx, dy, dz, h, e);
-            split_block_f16(e[0], xv[1], ovf);
-            const f32x16 hv = relu16(tiny_layer_h2<2>(w + 8, lds16(bias_h + 96), xv));   // view_linears on cat([feature, dirs]) (:152-156)
-            float r = 0.f, g = 0.f, b = 0.f;                                        // rgb_linear (:159-161)
-            {
-                const f32x16 r0 = lds16(sm + kKOffRgbW + h * 16), r1 = lds16(sm + kKOffRgbW + 32 + h * 16),
-                             r2 = lds16(sm + kKOffRgbW + 64 + h * 16);
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    r = fmaf(r0[t], hv[t], r);
-                    g = fmaf(r1[t], hv[t], g);
-                    b = fmaf(r2[t], hv[t], b);
-                }
+            if (!TABLE) {
+                encode_pe_doubling<4>(dx, dy, dz, h, e);
+                split_block_f16(e[0], xv[1], ovf);
             }
+            const f32x16 hv = relu16(tiny_layer_h2<2>(w + 8, lds16(bias_h + 96), xv));   // view_linears on cat([feature, dirs]) (:152-156)
+            // rgb_linear (:159-161)
+            float r = dot16(lds16(sm + kKOffRgbW + h * 16), hv), g = dot16(lds16(sm + kKOffRgbW + 32 + h * 16), hv),
+                  b = dot16(lds16(sm + kKOffRgbW + 64 + h * 16), hv);
             r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
-            ovf = fmaxf(ovf, __shfl_xor(ovf, 32));
+            ovf = fmaxf(fmaxf(ovf, dguard), __shfl_xor(ovf, 32));
             if (h == 0 && valid) {
                 float4 o = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
                 if (!(ovf < kF16Limit)) o = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
@@ -829,10 +884,12 @@ NRF_EXPORT int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_ce
 // MLP launch.
 static int kilo_forward_impl(bool h2, const KiloSrc* src, const int32_t* done, float* packed_t, const float* packed, int num_cells, const float* aabb_host,
                              const int* res_host, const float* pts, const float* dirs, const int32_t* dir_index,
-                             int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream_) {
+                             int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream_,
+                             const void* dir_table = nullptr, int64_t n_dirs = 0) {
     if (n_points < 0 || num_cells <= 0 || n_points > (1LL << 28)) return NRF_ERR_SHAPE;  // 32-bit byte offsets in the kernels
     if (n_points == 0) return NRF_OK;
-    if (!packed || !aabb_host || !res_host || !pts || !dirs || !raw || !workspace) return NRF_ERR_NULL;
+    if (!packed || !aabb_host || !res_host || !pts || !(dirs || dir_table) || !raw || !workspace) return NRF_ERR_NULL;
+    if (dir_table && (!dir_index || n_dirs <= 0 || n_dirs > (1LL << 24) || !nrf_aligned16(dir_table))) return NRF_ERR_SHAPE;   // 32-bit row offsets
     if (packed_t && !nrf_aligned16(packed_t)) return NRF_ERR_ALIGN;
     if (res_host[0] * res_host[1] * res_host[2] != num_cells || num_cells > 8192) return NRF_ERR_SHAPE;
     if (workspace_bytes < nrf_kilo_forward_workspace_bytes(n_points, num_cells)) return NRF_ERR_WORKSPACE;
@@ -860,19 +917,25 @@ static int kilo_forward_impl(bool h2, const KiloSrc* src, const int32_t* done, f
     }
     kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, job_tiles, seg_start, cursor, job_prefix);
     kilo_scatter_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(cell, n_points, num_cells, cursor, perm);
-    if (h2) {   // records from nrf_kilo_pack_weights_fp16x2
-        if (dir_index)
-            kilo_mlp_h2_kernel<true><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm,
-                                                                              pts, dirs, dir_index, reinterpret_cast<float4*>(raw));
+#define NRF_KILO_ARGS packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, dirs, dir_index, reinterpret_cast<float4*>(raw)
+    const dim3 grid(unsigned(2 * cus));
+    if (dir_table) {   // per-ray encodings (nrf_kilo_encode_dirs): `dirs` is not read
+        const float* tab = static_cast<const float*>(dir_table);
+        const float* guard = reinterpret_cast<const float*>(static_cast<const char*>(dir_table) + a256(n_dirs * kDirRowDwords * 4));
+        if (h2)
+            kilo_mlp_h2_kernel<true, true><<<grid, 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, tab,
+                                                                      dir_index, reinterpret_cast<float4*>(raw), guard);
         else
-            kilo_mlp_h2_kernel<false><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm,
-                                                                               pts, dirs, dir_index, reinterpret_cast<float4*>(raw));
+            kilo_mlp_kernel<true, true><<<grid, 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, tab,
+                                                                   dir_index, reinterpret_cast<float4*>(raw));
+    } else if (h2) {   // records from nrf_kilo_pack_weights_fp16x2
+        if (dir_index) kilo_mlp_h2_kernel<true, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS, nullptr);
+        else kilo_mlp_h2_kernel<false, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS, nullptr);
     } else if (dir_index)
-        kilo_mlp_kernel<true><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
-                                                                       dirs, dir_index, reinterpret_cast<float4*>(raw));
+        kilo_mlp_kernel<true, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS);
     else
-        kilo_mlp_kernel<false><<<dim3(unsigned(2 * cus)), 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts,
-                                                                        dirs, dir_index, reinterpret_cast<float4*>(raw));
+        kilo_mlp_kernel<false, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS);
+#undef NRF_KILO_ARGS
     return nrf_launch_status();
 }
 
@@ -890,6 +953,31 @@ NRF_EXPORT int nrf_kilo_forward_fp16x2(const float* packed_h2, int num_cells, co
                                        float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream) {
     return kilo_forward_impl(true, nullptr, nullptr, nullptr, packed_h2, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points,
                              raw, workspace, workspace_bytes, stream);
+}
+
+NRF_EXPORT int64_t nrf_kilo_dir_table_bytes(int64_t n_dirs) { return n_dirs <= 0 ? NRF_ERR_SHAPE : dir_table_bytes(n_dirs); }
+
+NRF_EXPORT int nrf_kilo_encode_dirs(const float* dirs, int64_t n_dirs, int fp16x2, void* table, nrf_stream_t stream) {
+    if (n_dirs < 0 || n_dirs > (1LL << 24)) return NRF_ERR_SHAPE;
+    if (n_dirs == 0) return NRF_OK;
+    if (!dirs || !table) return NRF_ERR_NULL;
+    if (!nrf_aligned16(table)) return NRF_ERR_ALIGN;
+    unsigned* tab = static_cast<unsigned*>(table);
+    float* guard = reinterpret_cast<float*>(static_cast<char*>(table) + a256(n_dirs * kDirRowDwords * 4));
+    const dim3 grid(unsigned((n_dirs + 127) / 128));
+    nrf_launch_begin();
+    if (fp16x2) kilo_dir_table_kernel<true><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(dirs, n_dirs, tab, guard);
+    else kilo_dir_table_kernel<false><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(dirs, n_dirs, tab, guard);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_kilo_forward_encoded(const float* packed, int fp16x2, int num_cells, const float* aabb_host, const int* res_host,
+                                        const float* pts, const void* dir_table, int64_t n_dirs, const int32_t* dir_index,
+                                        int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes,
+                                        nrf_stream_t stream) {
+    if (!dir_table || !dir_index) return NRF_ERR_NULL;
+    return kilo_forward_impl(fp16x2 != 0, nullptr, nullptr, nullptr, packed, num_cells, aabb_host, res_host, pts, nullptr, dir_index,
+                             n_points, raw, workspace, workspace_bytes, stream, dir_table, n_dirs);
 }
 
 NRF_EXPORT int nrf_kilo_pack_weights_fp16x2(const float* const* tensors, int num_cells, float* packed_h2, nrf_stream_t stream) {

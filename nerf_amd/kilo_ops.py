@@ -111,9 +111,26 @@ def kilo_packed_bwd_floats(num_cells: int) -> int:
     return int(lib().nrf_kilo_packed_bwd_floats(num_cells))
 
 
+def kilo_encode_dirs(dirs, kind: str = "fp32", out: torch.Tensor | None = None) -> torch.Tensor:
+    """The direction encodings of (m, 3) directions once per row (nrf_kilo_encode_dirs): a uint8 table for
+    kilo_forward(..., dir_table=...).  ``kind`` must be the kind of the forward that reads it."""
+    dirs = _f32(dirs, "dirs").reshape(-1, 3)
+    m = dirs.shape[0]
+    need = int(lib().nrf_kilo_dir_table_bytes(m)) if m else 0
+    if out is None or out.numel() < need:
+        out = torch.empty(max(need, 256), dtype=torch.uint8, device=dirs.device)
+    with torch.cuda.device(dirs.device):
+        check(lib().nrf_kilo_encode_dirs(_ptr(dirs), m, int(kind == "fp16x2"), _ptr(out), _stream(dirs)), "nrf_kilo_encode_dirs")
+    return out
+
+
 def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, workspace=None,
-                 return_workspace: bool = False, pack_from=None, packed_t=None, packed_cells=None, kind: str = "fp32"):
+                 return_workspace: bool = False, pack_from=None, packed_t=None, packed_cells=None, kind: str = "fp32",
+                 encode_dirs_per_ray: bool = True):
     """raw (n, 4) = [r, g, b, sigma] per point; dirs (n, 3) or (m, 3) with int32 dir_index (n,).
+    With ``dir_index`` (one direction per ray) the direction encodings are evaluated once per row of ``dirs`` and the
+    tiny-MLP kernel reads them from a table (nrf_kilo_encode_dirs + nrf_kilo_forward_encoded: bit-identical raw);
+    ``encode_dirs_per_ray=False`` keeps the per-point evaluation (nrf_kilo_forward / _fp16x2).
     ``kind`` "fp16x2": ``packed`` from kilo_pack_weights(kind="fp16x2"), the tiny MLPs on the fp16 matrix cores
     (fp32-class; operands beyond fp16's range give NaN).
     ``return_workspace``: also return the workspace (the points' order by cell), which kilo_backward needs.
@@ -151,6 +168,11 @@ def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, w
                                                  _ptr(pts), _ptr(dirs),
                                                  _ptr(dir_index), n, _ptr(raw), _ptr(workspace), workspace.numel(),
                                                  _stream(pts)), "nrf_kilo_forward_packing")
+        elif dir_index is not None and encode_dirs_per_ray and n > 0 and dirs.shape[0] <= (1 << 24):
+            table = kilo_encode_dirs(dirs, kind)
+            check(lib().nrf_kilo_forward_encoded(_ptr(packed), int(kind == "fp16x2"), num_cells, pa, pr, _ptr(pts), _ptr(table),
+                                                 dirs.shape[0], _ptr(dir_index), n, _ptr(raw), _ptr(workspace),
+                                                 workspace.numel(), _stream(pts)), "nrf_kilo_forward_encoded")
         else:
             fn = lib().nrf_kilo_forward if kind == "fp32" else lib().nrf_kilo_forward_fp16x2
             check(fn(_ptr(packed), num_cells, pa, pr, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,

@@ -114,6 +114,35 @@ def test_tiny_mlp_matches_oracle_sizes(dev, packed, n, spread):
     assert np.array_equal(raw_p, raw[perm])
 
 
+def test_per_ray_direction_table_is_bit_identical_to_per_point_encoding(dev, packed):
+    """nrf_kilo_encode_dirs + nrf_kilo_forward_encoded (direction features once per ray, read from a table) against
+    nrf_kilo_forward / _fp16x2 with the same dir_index (features re-evaluated per point, as the reference does,
+    network.py:243): the same device functions produce the operands, so raw must agree bit for bit -- ragged tails,
+    rays shared between tiles and cells, a ray nobody samples, both kernels."""
+    from nerf_amd import kilo_ops
+    packed, kind = packed
+    rng = np.random.default_rng(12)
+    n_rays = 700
+    dirs = rng.normal(size=(n_rays, 3)).astype(np.float32) * rng.uniform(0.2, 3.0, size=(n_rays, 1)).astype(np.float32)
+    for n in (1, 37, 20011):
+        pts = rng.uniform(-1.1, 1.1, size=(n, 3)).astype(np.float32)
+        di = np.sort(rng.integers(0, n_rays - 1, size=n)).astype(np.int32)          # ray n_rays - 1 has no sample
+        a = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev), _t(di, dev), kind=kind)
+        b = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev), _t(di, dev), kind=kind,
+                                  encode_dirs_per_ray=False)
+        c = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts, dev), _t(dirs[di], dev), kind=kind)   # per-point directions
+        assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c), (kind, n)
+    if kind == "fp16x2":   # the range guard travels with the table: a direction beyond fp16 refuses its ray's points only
+        pts = rng.uniform(-1, 1, size=(4096, 3)).astype(np.float32)
+        di = np.sort(rng.integers(0, n_rays, size=4096)).astype(np.int32)
+        clean = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts, dev), _t(dirs, dev), _t(di, dev), kind=kind)
+        bad = dirs.copy()
+        bad[di[2000], 2] = 1.0e5
+        out = kilo_ops.kilo_forward(packed, 4096, AABB, RES, _t(pts, dev), _t(bad, dev), _t(di, dev), kind=kind)
+        hit = torch.from_numpy(di == di[2000]).to(dev)
+        assert torch.isnan(out[hit]).all() and torch.equal(out[~hit], clean[~hit])
+
+
 def test_tiny_mlp_fp16x2_range_guard(dev):
     """Beyond fp16's range the fp16x2 kernel answers NaN, for the point (a huge coordinate) or for the cell (a huge
     weight), and leaves every other point's bits alone."""
