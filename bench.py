@@ -104,42 +104,51 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def _recorded(path: str, family: str, pick):
+    """A figure from a committed rocprofv3 PMC profile -- only while the profile was taken from the kernel sources that
+    are in the tree now (nerf_amd/source_hash.py: the profile stores their hash); (None, why) otherwise."""
+    from nerf_amd.source_hash import kernel_source_sha256
+    try:
+        with open(os.path.join(ROOT, "profiles", path)) as f:
+            prof = json.load(f)
+    except (OSError, ValueError):
+        return None, f"profiles/{path} absent"
+    if prof.get("kernel_source_sha256") != kernel_source_sha256(family):
+        return None, (f"profiles/{path} was recorded from other kernel sources than the ones in the tree (stale): "
+                      "re-run tools/run_bench_traffic.sh")
+    try:
+        return float(pick(prof)), f"profiles/{path} (same kernel sources as this build)"
+    except (KeyError, ValueError, TypeError):
+        return None, f"profiles/{path} unreadable"
+
+
+TRAFFIC_PROFILE = {"fp32": "r03_fp32_traffic_pmc.json", "bf16x3": "r03_bf16x3_traffic_pmc.json",
+                   "bf16": "r03_bf16_traffic_pmc.json", "fp16x2": "r03_fp16x2_traffic_pmc.json"}
+
+
 def recorded_traffic(dtype: str = "fp32"):
     """HBM bytes per MLP launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE,
-    MI355X_MICROARCH.md corrections): profiles/r01_mlp_traffic_pmc.json (mlp_fwd_kernel), r02_bf16x3_traffic_pmc.json
-    (mlp_bf16x3_kernel) or r02_bf16_traffic_pmc.json (mlp_bf16_kernel); tools/run_bench_traffic.sh collects them.
-    Counters cannot be read from inside the process, so this is the recorded figure, or None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", {"fp32": "r01_mlp_traffic_pmc.json", "bf16x3": "r02_bf16x3_traffic_pmc.json",
-                                           "bf16": "r02_bf16_traffic_pmc.json", "fp16x2": "r02_fp16x2_traffic_pmc.json"}[dtype])
-    try:
-        with open(path) as f:
-            return float(json.load(f)["traffic_bytes_per_launch_mean"])
-    except (OSError, KeyError, ValueError):
-        return None
+    MI355X_MICROARCH.md corrections; tools/run_bench_traffic.sh collects them, tools/bench_traffic_digest.py digests).
+    Counters cannot be read from inside the process, so this is the recorded figure -> (bytes or None, provenance)."""
+    return _recorded(TRAFFIC_PROFILE[dtype], dtype, lambda p: p["traffic_bytes_per_launch_mean"])
 
 
 def recorded_kilo_traffic(kind: str):
-    """HBM bytes of the KiloNeRF frame's tiny-MLP stage (route + cell scan + scatter + kilo_mlp kernel, one launch each per
-    frame) from the committed rocprofv3 PMC passes over the same frame (tools/run_pmc.sh ... kilo; FETCH_SIZE x2 +
-    WRITE_SIZE as for the other kernels): profiles/r02_kilo_h2_pmc.json (fp16x2) / r02_kilo_pmc.json (fp32)."""
-    path = os.path.join(ROOT, "profiles", "r02_kilo_pmc.json" if kind == "fp32" else "r02_kilo_h2_pmc.json")
-    try:
-        with open(path) as f:
-            kernels = json.load(f)["kernels"]
-        stage = [v["derived"]["hbm_bytes"] for k, v in kernels.items()
-                 if k.startswith(("kilo_route_kernel", "kilo_cell_scan_kernel", "kilo_scatter_kernel", "kilo_mlp_"))]
-        return float(sum(stage)) if len(stage) == 4 else None
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    """HBM bytes of the KiloNeRF frame's tiny-MLP stage (route + cell scan + scatter + direction table + kilo_mlp kernel,
+    one launch each per frame) from the committed rocprofv3 PMC passes over the same frame (tools/run_pmc.sh ... kilo;
+    FETCH_SIZE x2 + WRITE_SIZE as for the other kernels)."""
+    def pick(prof):
+        stage = [v["derived"]["hbm_bytes"] for k, v in prof["kernels"].items()
+                 if k.startswith(("kilo_route_kernel", "kilo_cell_scan_kernel", "kilo_scatter_kernel", "kilo_dir_table_kernel", "kilo_mlp_"))]
+        if len(stage) != 5:
+            raise KeyError("stage kernels")
+        return sum(stage)
+    return _recorded("r03_kilo_pmc.json" if kind == "fp32" else "r03_kilo_h2_pmc.json", "kilo", pick)
 
 
 def recorded_composite_traffic():
-    """Same for the fine compositing launch (profiles/r01_composite_traffic_pmc.json)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_composite_traffic_pmc.json")) as f:
-            return float(json.load(f)["traffic_bytes_fine_composite"])
-    except (OSError, KeyError, ValueError):
-        return None
+    """Same for the fine compositing launch."""
+    return _recorded("r03_composite_traffic_pmc.json", "composite", lambda p: p["traffic_bytes_fine_composite"])
 
 
 def cpu_baseline(seconds: float, dev=None, dtype="fp32"):
@@ -427,9 +436,8 @@ def kilo_bench(args, dev, rank, world, dist):
             "roofline": {"kernel": "kilo_forward (route + counting sort + %s)" % ("kilo_mlp_kernel" if kind == "fp32" else
                                    "kilo_mlp_h2_kernel: 3 fp16 MFMAs per fp32 product; peak = fp16 peak / 3"), "bound": "mfma",
                          "achieved": flop / (ms["mlp"] * 1e-3) / 1e12, "peak": PEAK_TFLOPS[kind], "unit": "TFLOP/s",
-                         "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / PEAK_TFLOPS[kind], "traffic": recorded_kilo_traffic(kind),
-                         "traffic_note": "HBM bytes of the stage's four kernels per frame from the committed PMC passes "
-                                         "(profiles/): ~91 B per evaluated sample, far from the HBM bound",
+                         "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / PEAK_TFLOPS[kind], "traffic": recorded_kilo_traffic(kind)[0],
+                         "traffic_note": "HBM bytes of the stage's kernels per frame (far from the HBM bound): " + recorded_kilo_traffic(kind)[1],
                          "samples_per_s": n / (ms["mlp"] * 1e-3)},
             "stage_ms": ms}
         if world == 1 and not args.no_cpu_baseline:
@@ -747,17 +755,18 @@ def render_bench(args, net, dev, rank, world, dist, dtype="fp32", steps=None, wa
         line["roofline"] = {
             "kernel": MLP_KERNEL[dtype],
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": recorded_traffic(dtype) if whole else None,
-            "traffic_note": "HBM bytes per launch (mean of coarse + fine) from the committed rocprofv3 PMC passes of this "
-                            "command at 1 GPU (profiles/); algorithmic bytes per launch %.4g"
-                            % (0.5 * mine * ((N_COARSE + N_COARSE + N_IMPORTANCE) * 16 + 48 + (N_COARSE + N_IMPORTANCE) * 4)),
+            "traffic": recorded_traffic(dtype)[0] if whole else None,
+            "traffic_note": "HBM bytes per launch (mean of coarse + fine) from rocprofv3 PMC passes of this command at 1 GPU: "
+                            "%s; algorithmic bytes per launch %.4g"
+                            % (recorded_traffic(dtype)[1], 0.5 * mine * ((N_COARSE + N_COARSE + N_IMPORTANCE) * 16 + 48 + (N_COARSE + N_IMPORTANCE) * 4)),
             "flop_per_launch": flop_launch, "ms_per_launch": ms_launch,
             "ms_coarse_launch": ms_mlp_c, "ms_fine_launch": ms_mlp_f, "measured_on": "rank 0, HIP events on the launch stream"}
         line["roofline_composite"] = {
             "kernel": "composite_kernel<3> (fine pass)", "bound": "hbm",
             "achieved": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": cmp_bytes / (ms_cmp_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": recorded_composite_traffic() if whole else None, "ms_per_launch": ms_cmp_f,
+            "traffic": recorded_composite_traffic()[0] if whole else None, "traffic_note": recorded_composite_traffic()[1],
+            "ms_per_launch": ms_cmp_f,
             "bytes_per_launch": cmp_bytes}
         line["stage_ms"] = {"mlp_coarse": ms_mlp_c, "composite_coarse": ms_cmp_c, "sample_fine": ms_smp,
                             "mlp_fine": ms_mlp_f, "composite_fine": ms_cmp_f}

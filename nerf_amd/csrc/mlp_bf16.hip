@@ -5,7 +5,12 @@
 // Numerics (the stated bf16 rule, restated in oracle/nerf_oracle.py:network_forward(bf16=True)):
 //   * matrix weights and every layer INPUT (encodings, relu'd hidden activations, the feature vector) are rounded
 //     to bf16 (round-to-nearest-even); products accumulate in fp32 on v_mfma_f32_32x32x16_bf16; biases are fp32
-//     accumulator initialisers; point construction, sin/cos, the alpha / rgb heads (fp32 weights, VALU) are fp32.
+//     accumulator initialisers; point construction, sin/cos and the rgb head (fp32 weights, VALU) are fp32;
+//   * the alpha head (256 -> 1) runs on the matrix pipe too, but with its weight NOT rounded: it travels as two bf16
+//     terms, w_hi = bf16(w) and w_lo = bf16(w - w_hi) (16 significand bits, 2^-17 relative), in rows 0 and 1 of one
+//     otherwise empty 32-row block behind feature_linear, its bias as that block's accumulator initialiser, and
+//     sigma = row 0 + row 1.  As a VALU dot product over the packed bf16 activations it was ~770 instructions per
+//     64-point tile that nothing overlapped (5.9 k of a tile's ~130 k cycles); as 16 k16-steps it is 1.35 % more MFMAs.
 //
 // Shape (what differs from the fp32 kernel): one MFMA now covers 16 k for 32 cycles (16x the fp32 rate), so the
 // weight stream and everything that is not an MFMA, not the matrix pipe, are the things to manage.  Activations live
@@ -41,11 +46,13 @@ constexpr int kBStepsL0 = 8 * 2 * 2;               // 8 out blocks x 2 PE k-bloc
 constexpr int kBStepsHidden = 8 * 8 * 2;           // 128
 constexpr int kBStepsSkip = 8 * 10 * 2;            // 160: per output block 2 PE k-blocks then 8 hidden
 constexpr int kBStepsViewsPad = 96;                // views: 4 x 9 x 2 = 72 used steps of 3 chunks
-constexpr int kBStreamSteps = kBStepsL0 + 7 * kBStepsHidden + kBStepsSkip + kBStepsViewsPad;  // 1184
-constexpr int kBChunks = kBStreamSteps / kBChunkSteps;                                         // 37
+constexpr int kBStepsAlphaPad = 32;                // alpha_linear as one 32-row block: 8 x 2 = 16 used steps of 1 chunk
+constexpr int kBStreamSteps = kBStepsL0 + 7 * kBStepsHidden + kBStepsSkip + kBStepsAlphaPad + kBStepsViewsPad;  // 1216
+constexpr int kBChunks = kBStreamSteps / kBChunkSteps;                                         // 38
 static_assert(kBStreamSteps % kBChunkSteps == 0, "stream must be whole chunks");
-// stream offsets (steps): pts0, pts1..4, pts5 (skip), pts6, pts7, feature, views
-constexpr int kBLayerStep[10] = {0, 32, 160, 288, 416, 544, 704, 832, 960, 1088};
+// stream offsets (steps): pts0, pts1..4, pts5 (skip), pts6, pts7, feature, views; the alpha block sits between the last two
+constexpr int kBLayerStep[10] = {0, 32, 160, 288, 416, 544, 704, 832, 960, 1120};
+constexpr int kBAlphaStep = 1088;
 constexpr int64_t kBSmallFloatOff = int64_t(kBStreamSteps) * 256;  // small block (fp32) behind the stream
 constexpr int kBLdsConstOff = kBRing * kBChunkBytes;               // 128 KiB
 constexpr int kBLdsBytes = kBLdsConstOff + kSmallFloats * 4;       // + 12.1 KiB
@@ -70,6 +77,7 @@ struct BPackLayer {
     int pre_kb, hid_kb, post_kb;
     int pre_L, post_L;
     int pre_col0, hid_col0, post_col0;
+    int split_row;   // != 0: W is ONE row (alpha_linear); block row 0 = bf16(w), row 1 = bf16(w - row 0), rows 2..31 = 0
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
@@ -88,7 +96,13 @@ __global__ void bpack_layer_kernel(BPackLayer p) {
         const int c = pe_col(kbpos * 16 + t, h, p.pre_L);
         if (c >= 0) v = p.W[row + p.pre_col0 + c];
     } else if (kbpos < p.pre_kb + p.hid_kb) {
-        v = p.W[row + p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
+        if (p.split_row) {
+            const int r = lane & 31;
+            const float wv = p.W[p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
+            v = r == 0 ? wv : (r == 1 ? __fsub_rn(wv, float((__bf16)wv)) : 0.f);
+        } else {
+            v = p.W[row + p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
+        }
     } else {
         const int c = pe_col((kbpos - p.pre_kb - p.hid_kb) * 16 + t, h, p.post_L);
         if (c >= 0) v = p.W[row + p.post_col0 + c];
@@ -244,7 +258,8 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
                                                    // MFMAs have drained by then)
     constexpr int PE = (NPRE + 7) * 2 - 1;         // the pending epilogue writes input block 7, first read at step
                                                    // (NPRE + 7) * 2: its last slice comes two steps earlier
-    static_assert(NOB % 2 == 0, "the last block must leave its accumulators in acc[1], the next layer starts in acc[0]");
+    static_assert(NOB % 2 == 0 || NOB == 1, "the last block must leave its accumulators in acc[1], the next layer starts in acc[0] "
+                                            "(NOB = 1, the alpha block: it stays in acc[0], the caller reads it, the next layer has no pending epilogue)");
     static_assert(!PEND || (NHID == 8 && PE > S0), "a pending epilogue needs a layer that reads 8 input blocks");
     static_assert(NSPAD % kBChunkSteps == 0 && NSPAD >= NS && NSPAD - NS < kBChunkSteps, "layer padding");
     static_assert(NS % kWQ == 0 && (NS % kBChunkSteps == 0 || (NS % kBChunkSteps) % 4 == 0) && (NS % kBChunkSteps == 0 || NS % kBChunkSteps > kLook),
@@ -330,9 +345,6 @@ __device__ __forceinline__ void bf_finish(Epi& epi, f32x16 (&acc)[2][NSETS]) {
     for (int q = 0; q < Epi::Q; ++q) epi.slice(NOB - 1, acc[(NOB - 1) & 1], q);
 }
 
-__device__ __forceinline__ float bf_lo(unsigned r) { return __uint_as_float(r << 16); }
-__device__ __forceinline__ float bf_hi(unsigned r) { return __uint_as_float(r & 0xffff0000u); }
-
 // Persistent, one workgroup of 8 / NSETS waves per CU (NSETS = 1: two waves per SIMD; NSETS = 2: one); a wave's tile =
 // 32 * NSETS consecutive samples of one ray, or (POINTS: Network.forward on a flat batch, network.py:184-186) that many
 // consecutive points with their own directions, used as given; then rays_o = pts (n, 3), rays_d = dirs (n, 3),
@@ -351,6 +363,12 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
         const float4* src = reinterpret_cast<const float4*>(packed + kBSmallFloatOff * 4);
         float4* dst = reinterpret_cast<float4*>(smem + kBLdsConstOff);
         for (int i = threadIdx.x; i < kSmallFloats / 4; i += 64 * WAVES) dst[i] = src[i];
+    }
+    __syncthreads();
+    {   // the alpha block's accumulator initialiser, [h][16] like every bias block: alpha_b in row 0, zeros elsewhere.  It
+        // takes the place of the head's fp32 weights in LDS, which this kernel no longer reads.
+        float* ab = reinterpret_cast<float*>(smem + kBLdsConstOff) + (kOffAlphaW - kOffBias);
+        if (threadIdx.x < 32) ab[threadIdx.x] = threadIdx.x == 0 ? ab[kOffAlphaB - kOffAlphaW] : 0.f;
     }
     __syncthreads();
     const float* cst = reinterpret_cast<const float*>(smem + kBLdsConstOff);
@@ -439,53 +457,42 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
             st.stamp_base = -1;
 #endif
         }
-        // XB = bf16(relu(h7)): alpha_linear, fp32 weights on the VALU
+        // XB = bf16(relu(h7)): alpha_linear as one more output block (rows 0 / 1 = the weight's two bf16 terms, bias in
+        // srcC); the layer also completes feature_linear's last block (pending in acc[1]) into XA.  Block 0 stays in
+        // acc[0]: sigma = row 0 + row 1 = registers 0 and 1 of lane half 0 (acc_row), read before views overwrites them.
+        // Register allocation: the VALU head that stood here read all of XB and thereby settled where XA / XB live through
+        // the pair loop; without such a use the allocator's choice spilled 112 registers per lane (and every scratch
+        // reload's vmcnt(0) drains the LDS-DMA ring).  Naming XB as accumulation registers here -- where the alpha block's
+        // MFMAs read it anyway -- restores a spill-free assignment (474 registers).
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set)
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+a"(XB[set][kb][s2]));
+        bf_layer<NSETS, 1, 0, 8, 0, kBStepsAlphaPad, true>(st, lane, cst + (kOffAlphaW - kOffBias) + h * 16, nullptr, XB, nullptr, toB, acc, toA);
         float sigma[NSETS];
 #pragma unroll
-        for (int set = 0; set < NSETS; ++set) sigma[set] = 0.f;
-        {
-            const float* aw = cst + (kOffAlphaW - kOffBias) + h * 16;
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
-#pragma unroll
-                for (int set = 0; set < NSETS; ++set)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const unsigned r = XB[set][kb][s2][i];
-                            sigma[set] = fmaf(w[8 * s2 + 2 * i], bf_lo(r), sigma[set]);
-                            sigma[set] = fmaf(w[8 * s2 + 2 * i + 1], bf_hi(r), sigma[set]);
-                        }
-            }
+        for (int set = 0; set < NSETS; ++set) {
+            sigma[set] = acc[0][set][0] + acc[0][set][1];
+            asm volatile("" : "+v"(sigma[set]));   // pinned here: sunk behind the views layer it would keep the block alive across it
         }
-        // (Folding these dot products into the block epilogues of pts_linears.7 was measured on the NSETS = 2 form: its
-        // layer body is shared with pts_linears.1 / .3, which then run the same 128 VALU instructions per block for
-        // nothing -- 109.0 vs 106.5 ms per fine pass; a private copy of the body does not fit the instruction cache.)
-        // Pin the alpha head HERE: LLVM otherwise sinks it to its use behind the views layer and keeps XB alive across
-        // it in scratch -- and every scratch reload's vmcnt(0) also drains the LDS-DMA ring (measured: 42 % of the
-        // kernel's wave time parked in s_waitcnt).
-#pragma unroll
-        for (int set = 0; set < NSETS; ++set) asm volatile("" : "+v"(sigma[set]));
         BF_STAMP_AT(11);
         // views_linears.0 on cat([feature (XA, no activation), dir PE]) -> 128, relu, rgb_linear
         EpiRgb<NSETS> er;
         er.rw = cst + (kOffRgbW - kOffBias) + h * 16;
 #pragma unroll
         for (int set = 0; set < NSETS; ++set) er.acc[set][0] = er.acc[set][1] = er.acc[set][2] = 0.f;
-        bf_layer<NSETS, 4, 0, 8, 1, kBStepsViewsPad, true>(st, lane, bias_h + 9 * 256, nullptr, XA, dpe, er, acc, toA);
+        bf_layer<NSETS, 4, 0, 8, 1, kBStepsViewsPad, false>(st, lane, bias_h + 9 * 256, nullptr, XA, dpe, er, acc, toA);
         bf_finish<NSETS, 4>(er, acc);
         BF_STAMP_AT(12);
         const float* rb = cst + (kOffRgbB - kOffBias);
-        const float ab = cst[kOffAlphaB - kOffBias];
 #pragma unroll
         for (int set = 0; set < NSETS; ++set) {
             float r = er.acc[set][0], g = er.acc[set][1], b = er.acc[set][2];
             r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32);
-            const float sg = sigma[set] + __shfl_xor(sigma[set], 32);
-            const int64_t dst = tile * TP + 32 * set + j;
-            if (h == 0 && valid && (!POINTS || dst < n_points)) raw[dst] = make_float4(r + rb[0], g + rb[1], b + rb[2], sg + ab);
+            const int64_t dst = tile * TP + 32 * set + j;   // (sigma is complete, bias included, in lane half 0)
+            if (h == 0 && valid && (!POINTS || dst < n_points)) raw[dst] = make_float4(r + rb[0], g + rb[1], b + rb[2], sigma[set]);
         }
         BF_STAMP_AT(13);
     }
@@ -504,21 +511,22 @@ NRF_EXPORT int nrf_pack_weights_bf16(const float* const* w, const float* const* 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     unsigned short* base = static_cast<unsigned short*>(packed);
     nrf_launch_begin();
-    (void)hipMemsetAsync(packed, 0, size_t(kBStreamSteps) * 1024, stream);  // views-layer padding steps stay zero
+    (void)hipMemsetAsync(packed, 0, size_t(kBStreamSteps) * 1024, stream);  // the alpha / views layers' padding steps stay zero
     auto launch = [&](BPackLayer p, int step0) {
         p.dst = base + int64_t(step0) * 512;
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
         bpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
     };
-    launch(BPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0}, kBLayerStep[0]);
+    launch(BPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0}, kBLayerStep[0]);
     for (int l = 1; l <= 7; ++l) {
         if (l == 5)  // network.py:58 cat([input_pts, h]): PE columns 0..62 then hidden 63..318, per output block
-            launch(BPackLayer{w[5], nullptr, 319, 8, 2, 8, 0, 10, 0, 0, 63, 0}, kBLayerStep[5]);
+            launch(BPackLayer{w[5], nullptr, 319, 8, 2, 8, 0, 10, 0, 0, 63, 0, 0}, kBLayerStep[5]);
         else
-            launch(BPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kBLayerStep[l]);
+            launch(BPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 0}, kBLayerStep[l]);
     }
-    launch(BPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0}, kBLayerStep[8]);     // feature_linear
-    launch(BPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256}, kBLayerStep[9]);   // views_linears.0
+    launch(BPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 0}, kBLayerStep[8]);     // feature_linear
+    launch(BPackLayer{w[9], nullptr, 256, 1, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kBAlphaStep);        // alpha_linear: one block, two-term weight
+    launch(BPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256, 0}, kBLayerStep[9]);  // views_linears.0
     PackSmall s;
     for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
     s.bias[8] = b[8];
