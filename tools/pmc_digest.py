@@ -3,7 +3,7 @@
 with the derived figures the DESIGN quotes (MFMA busy share, effective clock, wait shares, HBM traffic with the
 MI355X_MICROARCH.md corrections: FETCH_SIZE x2 on gfx950, both in KB).
 
-    python tools/pmc_digest.py gpurun_out/r02_bf16 [kernel-substring ...] > profiles/r02_bf16_pmc.json
+    python tools/pmc_digest.py gpurun_out/r02_bf16 [kernel-substring ...] [--family=kilo] > profiles/r02_bf16_pmc.json
 """
 import collections
 import csv
@@ -12,8 +12,10 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root = sys.argv[1]
-pats = sys.argv[2:]
+pats = [a for a in sys.argv[2:] if not a.startswith("--family=")]
+family = next((a.split("=", 1)[1] for a in sys.argv[2:] if a.startswith("--family=")), None)   # nerf_amd/source_hash.py
 rows = collections.defaultdict(dict)      # (kernel, pass) -> {dispatch: {counter: value, meta}}
 for path in sorted(glob.glob(os.path.join(root, "pmc*", "*counter_collection.csv"))):
     p = os.path.basename(os.path.dirname(path))
@@ -60,4 +62,8 @@ for short, r in out.items():
     if r.get("TCC_HIT_sum") is not None and r.get("TCC_MISS_sum") is not None:
         d["l2_hit_rate"] = r["TCC_HIT_sum"] / max(1.0, r["TCC_HIT_sum"] + r["TCC_MISS_sum"])
     r["derived"] = d
-json.dump({"source": root, "note": "longest dispatch per kernel per pass; counters are chip totals", "kernels": out}, sys.stdout, indent=1)
+doc = {"source": root, "note": "longest dispatch per kernel per pass; counters are chip totals", "kernels": out}
+if family:
+    from nerf_amd.source_hash import kernel_source_sha256
+    doc["kernel_source_sha256"] = kernel_source_sha256(family)   # bench.py reports figures of this profile only for these sources
+json.dump(doc, sys.stdout, indent=1)
