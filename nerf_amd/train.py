@@ -141,4 +141,16 @@ class TrainStep:
         self.t += 1
         ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.t, lr=self.lr, clip_value=self.clip,
                       grad_scale=scale)
+        self._bump_versions()
         return out
+
+    def _bump_versions(self):
+        """The optimiser kernel writes the flat buffer behind torch's back, so the parameters (views of it) would keep
+        their version counters -- and anything keyed on them would go on using the old weights: a ``Renderer`` over
+        the same network (the reference's trainer validates with one every epoch, trainer.py:111-147) caches its packed
+        weight streams per (data_ptr, _version).  Same contract as ``optimizer.step()``: every parameter's version
+        moves."""
+        bump = torch.autograd.graph.increment_version
+        for ws, bs in self.models:
+            for p in list(ws) + list(bs):
+                bump(p)
