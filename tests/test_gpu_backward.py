@@ -142,3 +142,50 @@ def test_clip_adam_matches_torch_over_steps(dev):
         opt.step()
         ops.clip_adam(p, grad.to(dev), m, v, step)
         assert np.abs(p.cpu().numpy() - ref.detach().numpy()).max() < 2e-6, step
+
+
+def test_fused_step_optimizer_state_round_trips_through_torch_adam(golden, dev):
+    """Checkpoint interop of the fused step (net_utils.py:288-340: 'optim' = torch.optim.Adam.state_dict() over
+    net.parameters()): after three fused steps the exported state, loaded into a REAL torch.optim.Adam over a twin
+    network, makes torch's fourth step land where the fused fourth step lands; and the state loads back bit for bit."""
+    from nerf_amd.network import Network
+    from nerf_amd.train import TrainStep
+    from nerf_amd.weights import make_state_dict
+    fx = golden("train_camera32")
+    sd0 = make_state_dict(int(fx["weight_seed"]), float(fx["density_gain"]), float(fx["density_bias"]))
+    net = Network()
+    net.load_state_dict(sd0)
+    ts = TrainStep(net.to(dev), dev)
+    ts.bins = _t(fx["t_bins"], dev)
+    args = [_t(fx[k], dev) for k in ("xyz", "viewdirs", "gt_rgb", "u", "u2", "u_coarse", "u_fine")]
+    for _ in range(3):
+        ts.step(*args)
+    state = ts.optimizer_state_dict()
+    assert len(state["param_groups"]) == 1 and len(state["param_groups"][0]["params"]) == 48 and len(state["state"]) == 48
+    assert all(float(s["step"]) == 3.0 for s in state["state"].values())
+    twin = Network()
+    twin.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    twin.to(dev)
+    opt = torch.optim.Adam(twin.parameters(), lr=5e-4, eps=1e-8)
+    opt.load_state_dict(state)                                   # the reference's resume (load_model)
+    ts.forward_backward(*args)                                   # gradients of step 4 at the current weights
+    flat = {p.data_ptr(): ts.grad[(p.data_ptr() - ts.flat.data_ptr()) // 4:][:p.numel()].view_as(p) for p in net.parameters()}
+    for p, q in zip(net.parameters(), twin.parameters()):
+        q.grad = flat[p.data_ptr()].clone()
+    torch.nn.utils.clip_grad_value_(list(twin.parameters()), 40.0)
+    opt.step()
+    ts.step(*args)
+    for (name, p), q in zip(net.named_parameters(), twin.parameters()):
+        assert float((p - q).abs().max()) < 2e-6, name           # the bar of test_clip_adam_matches_torch_over_steps
+    # ... and back: a fresh fused step resumes from the torch optimiser's state, bit for bit
+    net2 = Network()
+    net2.load_state_dict(sd0)
+    ts2 = TrainStep(net2.to(dev), dev)
+    ts2.load_optimizer_state_dict(opt.state_dict())
+    state4 = ts.optimizer_state_dict()
+    back = ts2.optimizer_state_dict()
+    assert ts2.t == 4 and ts.t == 4
+    for i in range(48):
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(back["state"][i][k], opt.state_dict()["state"][i][k]), (i, k)
+            assert float((state4["state"][i][k] - back["state"][i][k]).abs().max()) <= 1e-5 * float(state4["state"][i][k].abs().max() + 1e-30), (i, k)   # fused kernel vs torch: another association of the same products
