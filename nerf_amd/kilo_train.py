@@ -93,6 +93,22 @@ class KiloTrainStep:
         self.live.fill_(3)
         self._reg_moments = True
 
+    def optimizer_state_dict(self) -> dict:
+        """Adam state in the reference's checkpoint layout (one torch.optim.Adam group over net.parameters(),
+        src/train/optimizer.py:9-29): see nerf_amd.train.adam_state_dict."""
+        from .train import adam_state_dict, flat_slices
+        return adam_state_dict(flat_slices(self.net, self.flat), self.exp_avg, self.exp_avg_sq, self.t, self.lr)
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Resume from a checkpoint's 'optim' entry (net_utils.py:288-322).  Nothing is known about where foreign
+        moments are zero, so the per-cell skipping is switched off (every cell live in both bits)."""
+        from .train import flat_slices, load_adam_state_dict
+        self.t, lr = load_adam_state_dict(sd, flat_slices(self.net, self.flat), self.exp_avg, self.exp_avg_sq)
+        if lr is not None:
+            self.lr = lr
+        self.live.fill_(3)
+        self._reg_moments = True
+
     def _reachable_cells(self, occ, res):
         """int32 mask over the cells: 1 where some occupancy voxel inside the cell is set.  A hint, not a contract (the
         forward packs any cell the batch routes to that this mask misses); all ones when the occupancy grid is not a

@@ -28,6 +28,52 @@ def exponential_lr(base_lr: float, epoch: int, decay_epochs: int = 500, gamma: f
     return base_lr * gamma ** (epoch / decay_epochs)
 
 
+def flat_slices(net, flat: torch.Tensor):
+    """(parameter, offset, numel) in ``net.parameters()`` order for parameters that alias ``flat`` (fp32)."""
+    base, out = flat.data_ptr(), []
+    for p in net.parameters():
+        off = (p.data_ptr() - base) // 4
+        if not (0 <= off and off + p.numel() <= flat.numel()):
+            raise RuntimeError("a parameter of the network no longer aliases the step's flat buffer")
+        out.append((p, int(off), p.numel()))
+    return out
+
+
+def adam_state_dict(slices, exp_avg, exp_avg_sq, t: int, lr: float) -> dict:
+    """``torch.optim.Adam(net.parameters(), lr, eps=1e-8).state_dict()`` carrying flat moments (the reference's 'optim'
+    checkpoint entry: one group over net.parameters(), src/train/optimizer.py:9-29, net_utils.py:325-340); built by
+    filling a real torch optimiser, so the layout is the installed torch's."""
+    opt = torch.optim.Adam([p for p, _, _ in slices], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    if t > 0:
+        for p, off, n in slices:
+            opt.state[p] = {"step": torch.tensor(float(t)), "exp_avg": exp_avg[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": exp_avg_sq[off:off + n].view_as(p).clone()}
+    return opt.state_dict()
+
+
+def load_adam_state_dict(sd: dict, slices, exp_avg, exp_avg_sq):
+    """The inverse -> (step count, lr or None).  Parameters without state (a fresh optimiser) get zero moments."""
+    groups = sd.get("param_groups", [])
+    ids = [i for g in groups for i in g["params"]]
+    if len(ids) != len(slices):
+        raise ValueError(f"optimizer state over {len(ids)} parameters, this network has {len(slices)}")
+    exp_avg.zero_()
+    exp_avg_sq.zero_()
+    steps = set()
+    for i, (p, off, n) in zip(ids, slices):
+        st = sd["state"].get(i)
+        if st is None:
+            continue
+        if st["exp_avg"].numel() != n:
+            raise ValueError(f"optimizer state of parameter {i}: {tuple(st['exp_avg'].shape)} against {tuple(p.shape)}")
+        exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+        exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+        steps.add(int(float(st["step"])))
+    if len(steps) > 1:
+        raise ValueError(f"parameters at different Adam steps {sorted(steps)}: the fused kernel keeps one count")
+    return (steps.pop() if steps else 0), (float(groups[0]["lr"]) if groups else None)
+
+
 class TrainStep:
     def __init__(self, net, device, near=2.0, far=6.0, n_coarse=64, n_importance=128, white_bkgd=True,
                  lr=5e-4, clip_value=40.0, process_group=None, forward_dtype="fp32", backward_dtype=None,
@@ -147,53 +193,19 @@ class TrainStep:
     # ---- checkpoint interop: the reference saves optim.state_dict() of ONE torch.optim.Adam group over
     # net.parameters() (src/train/optimizer.py:9-29, src/utils/net_utils.py:325-340) and resumes from it (:288-322) ----
     def _flat_slices(self):
-        """(parameter, offset, numel) in net.parameters() order; offsets into the flat buffers."""
-        base, out = self.flat.data_ptr(), []
-        for p in self.net.parameters():
-            off = (p.data_ptr() - base) // 4
-            if not (0 <= off and off + p.numel() <= self.flat.numel()):
-                raise RuntimeError("a parameter of the network no longer aliases TrainStep's flat buffer")
-            out.append((p, int(off), p.numel()))
-        return out
+        return flat_slices(self.net, self.flat)
 
     def optimizer_state_dict(self) -> dict:
         """The step's Adam state as ``torch.optim.Adam(net.parameters(), lr, eps=1e-8).state_dict()`` would hold it after
-        the same steps (built by filling a real torch optimiser, so the layout is the installed torch's): what
-        ``checkpoint.save_model(..., optim_state=...)`` writes as ``'optim'`` for the reference's ``load_model``."""
-        params = [p for p, _, _ in self._flat_slices()]
-        opt = torch.optim.Adam(params, lr=self.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-        if self.t > 0:
-            for p, off, n in self._flat_slices():
-                opt.state[p] = {"step": torch.tensor(float(self.t)),
-                                "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
-                                "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
-        return opt.state_dict()
+        the same steps: what ``checkpoint.save_model(..., optim_state=...)`` writes as ``'optim'`` for the reference's
+        ``load_model``."""
+        return adam_state_dict(self._flat_slices(), self.exp_avg, self.exp_avg_sq, self.t, self.lr)
 
     def load_optimizer_state_dict(self, sd: dict) -> None:
-        """The inverse: resume from the ``'optim'`` entry of a checkpoint (this class's or the reference's own Adam over
-        the same network).  Parameters without state (a fresh optimiser) get zero moments."""
-        groups = sd.get("param_groups", [])
-        ids = [i for g in groups for i in g["params"]]
-        slices = self._flat_slices()
-        if len(ids) != len(slices):
-            raise ValueError(f"optimizer state over {len(ids)} parameters, this network has {len(slices)}")
-        self.exp_avg.zero_()
-        self.exp_avg_sq.zero_()
-        steps = set()
-        for i, (p, off, n) in zip(ids, slices):
-            st = sd["state"].get(i)
-            if st is None:
-                continue
-            if st["exp_avg"].numel() != n:
-                raise ValueError(f"optimizer state of parameter {i}: {tuple(st['exp_avg'].shape)} against {tuple(p.shape)}")
-            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-            steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise ValueError(f"parameters at different Adam steps {sorted(steps)}: the fused kernel keeps one count")
-        self.t = steps.pop() if steps else 0
-        if groups:
-            self.lr = float(groups[0]["lr"])
+        """Resume from the ``'optim'`` entry of a checkpoint (this class's or the reference's own Adam over the same network)."""
+        self.t, lr = load_adam_state_dict(sd, self._flat_slices(), self.exp_avg, self.exp_avg_sq)
+        if lr is not None:
+            self.lr = lr
 
     def _bump_versions(self):
         """The optimiser kernel writes the flat buffer behind torch's back, so the parameters (views of it) would keep

@@ -529,6 +529,16 @@ def test_fine_tuning_step_after_regularised_distillation_keeps_the_momentum(dev)
     # ... and moments loaded from elsewhere switch the skipping off altogether
     step.load_optimizer_state(m, v, 3)
     assert bool((step.live == 3).all())
+    # the reference's checkpoint layout (torch.optim.Adam over net.parameters()) out and back in
+    sd_opt = step.optimizer_state_dict()
+    assert len(sd_opt["param_groups"]) == 1 and len(sd_opt["state"]) == 12
+    opt = torch.optim.Adam(step.net.parameters(), lr=1.0)
+    opt.load_state_dict(sd_opt)                                   # a real torch optimiser accepts it (load_model's call)
+    m3, v3 = step.exp_avg.clone(), step.exp_avg_sq.clone()
+    step.exp_avg.zero_(), step.exp_avg_sq.zero_()
+    step.live.zero_()
+    step.load_optimizer_state_dict(opt.state_dict())
+    assert step.t == 3 and torch.equal(step.exp_avg, m3) and torch.equal(step.exp_avg_sq, v3) and bool((step.live == 3).all())
 
 
 def test_fused_call_grows_its_workspace_and_handles_empty_batches(dev):
