@@ -324,8 +324,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
         float* arow = nullptr;     // this lane's column of the tile's saved rows (mlp_fp32.hip)
         unsigned* mrow = nullptr;
         if (SAVE) {
+#ifdef NRF_ABL_L2WRAP   // timing only (tools/debug/lib_ab.sh): tiles share NRF_ABL_L2WRAP + 1 slots (7: L2-resident, 255: 83 MB)
+            arow = acts + (tile & NRF_ABL_L2WRAP) * (int64_t(kActRows) * 32) + 4 * h * 32 + j;
+            mrow = masks + (tile & NRF_ABL_L2WRAP) * (kMaskLayers * 4 * 64) + lane;
+#else
             arow = acts + tile * (int64_t(kActRows) * 32) + 4 * h * 32 + j;
             mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+#endif
         }
         {
             const f32x16 e0 = encode_block<10, 0>(px, py, pz, h), e1 = encode_block<10, 1>(px, py, pz, h);
@@ -424,7 +429,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_x3_kernel(const float* __res
         float4 g = graw[pidx];
         if (!valid) g = make_float4(0.f, 0.f, 0.f, 0.f);
         const unsigned* mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+#ifdef NRF_ABL_L2WRAP
+        float* drow = dys + (tile & NRF_ABL_L2WRAP) * (int64_t(kDyRows) * 32) + 4 * h * 32 + j;
+#else
         float* drow = dys + tile * (int64_t(kDyRows) * 32) + 4 * h * 32 + j;
+#endif
         if (h == 0) {  // d(raw) as 4 rows for the head wgrad jobs
             float* r = dys + tile * (int64_t(kDyRows) * 32) + kDyRaw * 32 + j;
             r[0] = g.x, r[32] = g.y, r[64] = g.z, r[96] = g.w;

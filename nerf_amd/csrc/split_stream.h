@@ -112,8 +112,15 @@ struct OpInBase {
         return;
 #endif
         const int t0 = 2 * q, t1 = 2 * q + 1;
-        save[(32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32] = SCALED ? a * kscale : a;
-        save[(32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32] = SCALED ? b * kscale : b;
+#ifdef NRF_ABL_FAKESTORE   // timing only (tools/debug/lib_ab.sh): the values and sign words are made, the row stores are not issued
+        asm volatile("" ::"v"(SCALED ? a * kscale : a), "v"(SCALED ? b * kscale : b));
+#elif defined(NRF_ABL_STORE2)   // timing only: the same bytes and lines with one 8-byte store per pair (wrong layout)
+        *reinterpret_cast<float2*>(save + (32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32 + (threadIdx.x & 31)) =
+            make_float2(SCALED ? a * kscale : a, SCALED ? b * kscale : b);
+#else
+        save_row(save + (32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32, SCALED ? a * kscale : a);
+        save_row(save + (32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32, SCALED ? b * kscale : b);
+#endif
         if (MODE == kOpFwdSave && msave) {
             if (q == 0) mcur = 0u;
             mcur |= ((a > 0.f ? 1u : 0u) << t0) | ((b > 0.f ? 1u : 0u) << t1);   // (as min(bits, 1) << t | mcur: no faster)
