@@ -22,8 +22,8 @@ terms (3 x 8 = 24 significand bits) and each product as six bf16 MFMAs -- and `d
 fp32 MFMA kernel (also 24-bit operands); `--dtype fp16x2` is the narrower form (two fp16 terms = 22 significand bits,
 three MFMAs per product: less than the reference's arithmetic, so never the headline).  The default line carries the
 other two frames as `also.fp32_frame` and `also.fp16x2_frame`, and the training step / KiloNeRF frame in the 24-bit
-dtype first (`also.train_step`, `also.kilo_frame`) with their fp16x2 forms beside them (`also.train_step_fp16x2`,
-`also.kilo_frame_fp16x2`).
+dtype first (`also.train_step`, `also.kilo_frame`: bf16x3 both; `also.kilo_frame_fp32` is the fp32 MFMA kernel's frame)
+with their fp16x2 forms beside them (`also.train_step_fp16x2`, `also.kilo_frame_fp16x2`).
 
 The same JSON line carries
   roofline      the dominant kernel (MFMA-bound): algorithmic FLOPs of the fp32 problem per launch
@@ -143,7 +143,7 @@ def recorded_kilo_traffic(kind: str):
         if len(stage) != 5:
             raise KeyError("stage kernels")
         return sum(stage)
-    return _recorded("r03_kilo_pmc.json" if kind == "fp32" else "r03_kilo_h2_pmc.json", "kilo", pick)
+    return _recorded({"fp32": "r03_kilo_pmc.json", "fp16x2": "r03_kilo_h2_pmc.json", "bf16x3": "r03_kilo_x3_pmc.json"}[kind], "kilo", pick)
 
 
 def recorded_composite_traffic():
@@ -370,7 +370,8 @@ def kilo_bench(args, dev, rank, world, dist):
     net.to(dev)
     c = (torch.arange(256, device=dev, dtype=torch.float32) + 0.5) / 256 * 2 - 1
     occ = ((c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2).sqrt() < 0.75).to(torch.uint8)
-    kind = "fp16x2" if args.dtype == "fp16x2" else "fp32"    # default: the reference's fp32 arithmetic (fp32 MFMA kernel)
+    # the tiny MLPs' arithmetic: fp32 MFMA kernel, the same 24-bit operands as three bf16 terms (bf16x3), or fp16x2 (22-bit)
+    kind = args.dtype if args.dtype in ("fp16x2", "bf16x3") else "fp32"
     r = KiloRenderer(net, default_kilo_cfg(), occ, mlp_dtype=kind)
     poses = test_set_poses(200)
     focal = focal_from_angle(W)
@@ -428,13 +429,14 @@ def kilo_bench(args, dev, rank, world, dist):
             "metric": "rays/sec (KiloNeRF 800x800 frame, occupancy-grid marching + early termination)",
             "value": world * R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if kind == "fp32" else DTYPE_LABEL["fp16x2"],
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL[kind],
             "data": "synthetic (orbit camera, random-init cells, sigma head x10 + 0.5, sphere occupancy)",
             "config": {"workload": "BASELINE configs[3]: KiloNeRF 16^3 cells W=32 D=2, sphere |x|<0.75 occupancy at 256^3, "
                                    "step 0.005, ERT 0.01, 800x800 view per rank per step", "rays_per_frame": R,
                        "samples_per_frame": n, "samples_per_hit_ray": n / max(1.0, float((out[2] > 0).sum()))},
-            "roofline": {"kernel": "kilo_forward (route + counting sort + %s)" % ("kilo_mlp_kernel" if kind == "fp32" else
-                                   "kilo_mlp_h2_kernel: 3 fp16 MFMAs per fp32 product; peak = fp16 peak / 3"), "bound": "mfma",
+            "roofline": {"kernel": "kilo_forward (route + counting sort + %s)" % {
+                "fp32": "kilo_mlp_kernel", "fp16x2": "kilo_mlp_h2_kernel: 3 fp16 MFMAs per fp32 product; peak = fp16 peak / 3",
+                "bf16x3": "kilo_mlp_x3_kernel: 6 bf16 MFMAs per fp32 product; peak = bf16 peak / 6"}[kind], "bound": "mfma",
                          "achieved": flop / (ms["mlp"] * 1e-3) / 1e12, "peak": PEAK_TFLOPS[kind], "unit": "TFLOP/s",
                          "frac": flop / (ms["mlp"] * 1e-3) / 1e12 / PEAK_TFLOPS[kind], "traffic": recorded_kilo_traffic(kind)[0],
                          "traffic_note": "HBM bytes of the stage's kernels per frame (far from the HBM bound): " + recorded_kilo_traffic(kind)[1],
@@ -800,13 +802,14 @@ def also_block(args, net, dev):
     out["bf16_frame"] = cut(render_bench(sub, net, dev, 0, 1, None, dtype="bf16", steps=5, warmup=1, cpu=False))
     torch.cuda.empty_cache()
     # configs[2] / configs[3] in 24-bit-operand arithmetic first (the reference's: bf16x3 matrix work for the training
-    # step, the fp32 MFMA kernel for the KiloNeRF tiny MLPs), their narrower fp16x2 forms beside them
+    # step and the KiloNeRF tiny MLPs), their narrower fp16x2 forms beside them
     wide = "fp32" if args.dtype == "fp32" else "bf16x3"
     for key, dtype in (("train_step", wide), ("train_step_fp16x2", "fp16x2")):
         sub.steps, sub.warmup, sub.dtype = 20, 3, dtype
         out[key] = cut(train_bench(sub, copy_network(net, dev), dev, 0, 1, None))
         torch.cuda.empty_cache()
-    for key, dtype in (("kilo_frame", "fp32"), ("kilo_frame_fp16x2", "fp16x2")):
+    # (KiloNeRF: the three-term bf16 kernel is the faster of the two 24-bit forms; the fp32 MFMA kernel's frame beside it)
+    for key, dtype in (("kilo_frame", "bf16x3"), ("kilo_frame_fp32", "fp32"), ("kilo_frame_fp16x2", "fp16x2")):
         sub.steps, sub.warmup, sub.dtype = 20, 3, dtype
         out[key] = cut(kilo_bench(sub, dev, 0, 1, None))
         torch.cuda.empty_cache()

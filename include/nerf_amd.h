@@ -289,17 +289,28 @@ int nrf_kilo_forward_fp16x2(const float* packed_h2, int num_cells, const float* 
                             const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points, float* raw,
                             void* workspace, int64_t workspace_bytes, nrf_stream_t stream);
 
+/* The same two calls at fp32 accuracy on the bf16 matrix cores (network.py:123-167 again): every weight and layer input
+ * as THREE bf16 terms (a fp32 value is exactly their sum), the six products w_i x_j with i + j <= 2 as six
+ * v_mfma_f32_32x32x16_bf16 per fp32 product, added small terms first into one fp32 accumulator; fp32 biases and heads
+ * (the "bf16x3" rule of nrf_mlp_forward_rays_bf16x3: fp32's 24 significand bits and fp32's range, no guard).
+ * packed_x3 has nrf_kilo_packed_bf16x3_floats(num_cells) floats (36 KiB of fragments + the small block per cell). */
+int64_t nrf_kilo_packed_bf16x3_floats(int num_cells);
+int nrf_kilo_pack_weights_bf16x3(const float* const* tensors_host, int num_cells, float* packed_x3, nrf_stream_t stream);
+int nrf_kilo_forward_bf16x3(const float* packed_x3, int num_cells, const float* aabb_host, const int* res_host,
+                            const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points, float* raw,
+                            void* workspace, int64_t workspace_bytes, nrf_stream_t stream);
+
 /* Network.forward with the direction encodings evaluated once per RAY instead of once per point.  The reference expands
  * viewdirs per point and embeds every copy (network.py:243, 276-283); the 27 direction features depend on the ray only.
- * nrf_kilo_encode_dirs writes, per row of dirs (n_dirs, 3), the view layer's direction operands exactly as the kernels'
- * lanes would compute them (fp16x2 != 0: as the two-term fp16 fragments of nrf_kilo_forward_fp16x2, plus the range
- * guard's maximum per row) into `table` (nrf_kilo_dir_table_bytes(n_dirs) bytes, 16-byte aligned, 132 B per row);
- * nrf_kilo_forward_encoded is nrf_kilo_forward / nrf_kilo_forward_fp16x2 (fp16x2 selects; `packed` accordingly) reading
- * that table through dir_index (required) -- bit-identical raw, ~100 fewer VALU instructions per 32-point tile.
- * n_dirs <= 2^24. */
+ * `kind` names the records / kernel: 0 = nrf_kilo_forward (fp32), 1 = nrf_kilo_forward_fp16x2, 2 = nrf_kilo_forward_bf16x3.
+ * nrf_kilo_encode_dirs writes, per row of dirs (n_dirs, 3), the view layer's direction operands exactly as that kernel's
+ * lanes would compute them (kind 1: the two-term fp16 fragments plus the range guard's maximum per row; kind 2: the
+ * three-term bf16 fragments) into `table` (nrf_kilo_dir_table_bytes(n_dirs) bytes, 16-byte aligned; one size for every
+ * kind: 196 B per row); nrf_kilo_forward_encoded is that kind's forward (`packed` accordingly) reading the table through
+ * dir_index (required) -- bit-identical raw, ~100 fewer VALU instructions per 32-point tile.  n_dirs <= 2^24. */
 int64_t nrf_kilo_dir_table_bytes(int64_t n_dirs);
-int nrf_kilo_encode_dirs(const float* dirs, int64_t n_dirs, int fp16x2, void* table, nrf_stream_t stream);
-int nrf_kilo_forward_encoded(const float* packed, int fp16x2, int num_cells, const float* aabb_host, const int* res_host,
+int nrf_kilo_encode_dirs(const float* dirs, int64_t n_dirs, int kind, void* table, nrf_stream_t stream);
+int nrf_kilo_forward_encoded(const float* packed, int kind, int num_cells, const float* aabb_host, const int* res_host,
                              const float* pts, const void* dir_table, int64_t n_dirs, const int32_t* dir_index,
                              int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream);
 

@@ -21,6 +21,7 @@
 
 #include "kilo_common.h"
 #include "split2h.h"
+#include "split3.h"
 
 namespace {
 
@@ -226,10 +227,12 @@ __global__ __launch_bounds__(256) void kilo_scatter_kernel(const int* __restrict
 // produced by the same device functions, so a table-fed tile is bit-identical to a self-encoding one.  A tile loads its
 // 64 B per lane at its top (four global_load_dwordx4; neighbouring points share rays, so the rows come from L1 / L2) and
 // uses them three layers later.
-constexpr int kDirRowDwords = 32;
-__attribute__((unused)) inline int64_t dir_table_bytes(int64_t n_dirs) { return a256(n_dirs * kDirRowDwords * 4) + a256(n_dirs * 4); }
+constexpr int kDirRowDwordsMax = 48;   // the bf16x3 form's rows: [k16-step][term] x 4 dwords per lane half (below)
+// one size for every form: rows of the widest form, then the fp16 form's guard column
+__attribute__((unused)) inline int64_t dir_guard_offset(int64_t n_dirs) { return a256(n_dirs * kDirRowDwordsMax * 4); }
+__attribute__((unused)) inline int64_t dir_table_bytes(int64_t n_dirs) { return dir_guard_offset(n_dirs) + a256(n_dirs * 4); }
 
-template <bool H2>
+template <int KIND>   // 0: fp32 slots, 1: fp16x2 fragments + guard, 2: bf16x3 fragments (48 dwords per row)
 __global__ __launch_bounds__(256) void kilo_dir_table_kernel(const float* __restrict__ dirs, int64_t n_dirs,
                                                              unsigned* __restrict__ table, float* __restrict__ guard) {
     const int lane = threadIdx.x & 63;
@@ -238,14 +241,20 @@ __global__ __launch_bounds__(256) void kilo_dir_table_kernel(const float* __rest
     const int64_t src = row < n_dirs ? row : n_dirs - 1;   // every lane runs (the encoding swaps between lane halves)
     f32x16 e[1];
     encode_pe_doubling<4>(dirs[src * 3], dirs[src * 3 + 1], dirs[src * 3 + 2], h, e);
-    u32x4 out[4];
-    if (H2) {
+    constexpr int NQ = KIND == 2 ? 6 : 4;
+    u32x4 out[NQ];
+    if constexpr (KIND == 1) {
         float ovf = 0.f;
         u32x4 f[2][2];
         split_block_f16(e[0], f, ovf);
         out[0] = f[0][0], out[1] = f[0][1], out[2] = f[1][0], out[3] = f[1][1];
         ovf = fmaxf(ovf, __shfl_xor(ovf, 32));
         if (row < n_dirs && h == 0) guard[row] = ovf;
+    } else if constexpr (KIND == 2) {
+        u32x4 f[2][3];
+        split_block_x3(SplitSel::make(), e[0], f);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) out[q] = f[q / 3][q % 3];
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -253,9 +262,9 @@ __global__ __launch_bounds__(256) void kilo_dir_table_kernel(const float* __rest
             for (int c = 0; c < 4; ++c) out[q][c] = __float_as_uint(e[0][4 * q + c]);
     }
     if (row < n_dirs) {
-        u32x4* dst = reinterpret_cast<u32x4*>(table + (row * 2 + h) * 16);
+        u32x4* dst = reinterpret_cast<u32x4*>(table + (row * 2 + h) * (NQ * 4));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = out[q];
+        for (int q = 0; q < NQ; ++q) dst[q] = out[q];
     }
 }
 
@@ -282,7 +291,7 @@ __device__ __forceinline__ float dot16(const f32x16& w, const f32x16& x) {
 // the SIMD's issue cycles, so more waves do not help -- a workgroup-shared LDS copy of the whole cell record with
 // four waves per SIMD (112 registers) measured 3.5 ms.  Only fewer instructions per tile would.
 template <bool INDEXED, bool TABLE>  // directions gathered through dir_index (one per ray) or given per point; TABLE:
-                                     // `dirs` is the per-ray encoding table of kilo_dir_table_kernel<false> (INDEXED only)
+                                     // `dirs` is the per-ray encoding table of kilo_dir_table_kernel<0> (INDEXED only)
 __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
                                                           const int* __restrict__ seg_start,
                                                           const int* __restrict__ job_prefix,
@@ -292,7 +301,8 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
+    const int wave_global = blockIdx.x * 4 + wave;
     const int n_waves = gridDim.x * 4;
     const int total_jobs = job_prefix[ncell];
     for (int job = wave_global; job < total_jobs; job += n_waves) {
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
         // biases and head rows (288 floats) go to this wave's LDS slice and are re-read per tile: as 128 more live
         // registers they pushed the kernel past 256 VGPRs, every layer's output landed in AGPRs and came back one
         // v_accvgpr_read at a time (69 per tile).  Wave-private region: no barrier, the wave's own LDS order suffices.
-        float* sm_job = s_small[threadIdx.x >> 6];
+        float* sm_job = s_small[wave];
         {
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloSteps * 256);
             reinterpret_cast<float4*>(sm_job)[lane] = src[lane];
@@ -484,7 +494,7 @@ __device__ __forceinline__ f32x16 tiny_layer_h2(const u32x4 (*w)[2], f32x16 init
 
 // kilo_mlp_kernel with the cell's matrices as fp16x2 fragments (96 registers, as before).  Points whose operands leave
 // fp16's range, and every point of a cell with such a weight, come out as NaN (mlp_fp16x2.hip's guard).
-template <bool INDEXED, bool TABLE>   // TABLE: `dirs` is the table of kilo_dir_table_kernel<true>, `dir_guard` its range-guard column
+template <bool INDEXED, bool TABLE>   // TABLE: `dirs` is the table of kilo_dir_table_kernel<1>, `dir_guard` its range-guard column
 __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
                                                              const int* __restrict__ seg_start,
                                                              const int* __restrict__ job_prefix,
@@ -495,7 +505,8 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
+    const int wave_global = blockIdx.x * 4 + wave;
     const int n_waves = gridDim.x * 4;
     const int total_jobs = job_prefix[ncell];
     for (int job = wave_global; job < total_jobs; job += n_waves) {
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
             w[s][0] = reinterpret_cast<const u32x4*>(cw)[(2 * s) * 64 + lane];
             w[s][1] = reinterpret_cast<const u32x4*>(cw)[(2 * s + 1) * 64 + lane];
         }
-        float* sm_job = s_small[threadIdx.x >> 6];   // wave-private: no barrier (kilo_mlp_kernel)
+        float* sm_job = s_small[wave];   // wave-private: no barrier (kilo_mlp_kernel)
         {
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloSteps * 256);
             reinterpret_cast<float4*>(sm_job)[lane] = src[lane];
@@ -596,6 +607,207 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
                 if (!(ovf < kF16Limit)) o = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
                 raw[id] = o;
             }
+        }
+    }
+}
+
+// ---- the tiny MLPs on the bf16 matrix cores at fp32 accuracy (three bf16 terms per operand, split3.h / mlp_bf16x3.hip) ----
+// fp32 w = w0 + w1 + w2 exactly (3 x 8 significand bits), a product keeps the six terms w_i x_j with i + j <= 2, added small
+// terms first into ONE fp32 accumulator: 72 v_mfma_f32_32x32x16_bf16 per 32-point tile (2.3 k matrix-pipe cycles) where the
+// fp32 form has 96 v_mfma_f32_32x32x2_f32 (6.1 k), at the fp32 form's accuracy and range (no guard, no status word).
+// Record: 12 k16-steps of (hi | mid | lo) fragments = 36 KiB + the fp32 kernel's small block.  hi and mid stay in registers
+// for the job (96, as the other two kernels); the lo fragments -- one of a step's six MFMAs reads them -- sit in a
+// wave-private LDS slice (12 KiB per wave, each lane re-reads only what it wrote: no barrier) so that two waves per SIMD fit.
+constexpr int kKX3Steps = 12;
+constexpr int kKiloX3MatFloats = kKX3Steps * 3 * 256;                 // 9216
+constexpr int kKiloCellFloatsX3 = kKiloX3MatFloats + kKiloSmall;      // 9504
+
+
+__global__ __launch_bounds__(256) void kilo_pack_x3_kernel(KiloSrc s, int num_cells, float* __restrict__ packed) {
+    __shared__ float rec[kRecFloats];
+    const int cell = blockIdx.x;
+    stage_cell_record(s, cell, rec);
+    __syncthreads();
+    unsigned short* frag = reinterpret_cast<unsigned short*>(packed + int64_t(cell) * kKiloCellFloatsX3);
+    for (int idx = threadIdx.x; idx < kKX3Steps * 512; idx += 256) {   // same (step, lane, element) -> weight map as kilo_pack_h2_kernel
+        const int jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
+        const int h = lane >> 5, row = lane & 31;
+        float v = 0.f;
+        if (step < 4) {
+            const int c = pe_col((step >> 1) * 16 + 8 * (step & 1) + jj, h, 10);
+            if (c >= 0) v = rec[REC_OFF(0) + row * 63 + c];
+        } else if (step < 6) {
+            v = rec[REC_OFF(2) + row * 32 + acc_row(8 * (step & 1) + jj, h)];
+        } else if (step < 8) {
+            v = rec[REC_OFF(4) + row * 32 + acc_row(8 * (step & 1) + jj, h)];
+        } else if (step < 10) {
+            v = rec[REC_OFF(8) + row * 59 + acc_row(8 * (step & 1) + jj, h)];
+        } else {
+            const int c = pe_col(8 * (step & 1) + jj, h, 4);
+            if (c >= 0) v = rec[REC_OFF(8) + row * 59 + 32 + c];
+        }
+        const __bf16 b0 = (__bf16)v;
+        const float r1 = __fsub_rn(v, (float)b0);
+        const __bf16 b1 = (__bf16)r1;
+        const __bf16 b2 = (__bf16)__fsub_rn(r1, (float)b1);
+        frag[step * 1536 + lane * 8 + jj] = __builtin_bit_cast(unsigned short, b0);
+        frag[step * 1536 + 512 + lane * 8 + jj] = __builtin_bit_cast(unsigned short, b1);
+        frag[step * 1536 + 1024 + lane * 8 + jj] = __builtin_bit_cast(unsigned short, b2);
+    }
+    for (int i = threadIdx.x; i < kKiloSmall; i += 256) {   // the fp32 kernel's small block (kilo_pack_kernel)
+        float v = 0.f;
+        if (i < 128) {
+            const int layer = i >> 5, h = (i >> 4) & 1, r = i & 15;
+            const int off = layer == 0 ? REC_OFF(1) : layer == 1 ? REC_OFF(3) : layer == 2 ? REC_OFF(5) : REC_OFF(9);
+            v = rec[off + acc_row(r, h)];
+        } else if (i < 160) {
+            const int h = ((i - 128) >> 4) & 1, r = i & 15;
+            v = rec[REC_OFF(6) + acc_row(r, h)];
+        } else if (i < 256) {
+            const int j = i - 160, c = j >> 5, h = (j >> 4) & 1, r = j & 15;
+            v = rec[REC_OFF(10) + c * 32 + acc_row(r, h)];
+        } else if (i == kKOffSigB) {
+            v = rec[REC_OFF(7)];
+        } else if (i < kKOffRgbB + 3) {
+            v = rec[REC_OFF(11) + (i - kKOffRgbB)];
+        }
+        packed[int64_t(cell) * kKiloCellFloatsX3 + kKiloX3MatFloats + i] = v;
+    }
+}
+
+// One 32x32 output block of a tiny layer on the bf16 pipe, six MFMAs per k16-step into one accumulator, small terms first
+// (mlp_bf16x3.hip's order); `wlo`: this lane's lo fragments in LDS, 64 u32x4 per step.
+template <int NKB>
+__device__ __forceinline__ f32x16 tiny_layer_x3(const u32x4 (*w)[2], const u32x4* wlo, f32x16 init, const u32x4 (*x)[2][3]) {
+    f32x16 y = init;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int st = kb * 2 + s2;
+            const u32x4 w2 = wlo[st * 64];
+            y = NRF_MFMA_X3(w2, x[kb][s2][0], y);
+            y = NRF_MFMA_X3(w[st][0], x[kb][s2][2], y);
+            y = NRF_MFMA_X3(w[st][1], x[kb][s2][1], y);
+            y = NRF_MFMA_X3(w[st][1], x[kb][s2][0], y);
+            y = NRF_MFMA_X3(w[st][0], x[kb][s2][1], y);
+            y = NRF_MFMA_X3(w[st][0], x[kb][s2][0], y);
+        }
+    return y;
+}
+
+template <bool INDEXED, bool TABLE>   // TABLE: `dirs` is the table of kilo_dir_table_kernel<2>
+__global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __restrict__ packed, int ncell, int job_tiles,
+                                                             const int* __restrict__ seg_start,
+                                                             const int* __restrict__ job_prefix,
+                                                             const int* __restrict__ perm, const float* __restrict__ pts,
+                                                             const float* __restrict__ dirs,
+                                                             const int* __restrict__ dir_index, float4* __restrict__ raw) {
+    __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
+    __shared__ u32x4 s_wlo[4][kKX3Steps][64];
+    const SplitSel sel = SplitSel::make();
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
+    const int wave_global = blockIdx.x * 4 + wave;
+    const int n_waves = gridDim.x * 4;
+    const int total_jobs = job_prefix[ncell];
+    for (int job = wave_global; job < total_jobs; job += n_waves) {
+        int lo = 0, hi = ncell;   // cell of this job: last c with job_prefix[c] <= job
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (job_prefix[mid] <= job) lo = mid; else hi = mid;
+        }
+        const int cell = lo;
+        const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
+        const int first = seg_b + (job - job_prefix[cell]) * 32 * job_tiles;
+        const float* cw = packed + int64_t(cell) * kKiloCellFloatsX3;
+        u32x4 w[kKX3Steps][2];
+        u32x4* wlo_job = &s_wlo[wave][0][lane];   // lane-private slots: the wave's own LDS order suffices
+#pragma unroll
+        for (int s = 0; s < kKX3Steps; ++s) {
+            w[s][0] = reinterpret_cast<const u32x4*>(cw)[(3 * s) * 64 + lane];
+            w[s][1] = reinterpret_cast<const u32x4*>(cw)[(3 * s + 1) * 64 + lane];
+            wlo_job[s * 64] = reinterpret_cast<const u32x4*>(cw)[(3 * s + 2) * 64 + lane];
+        }
+        float* sm_job = s_small[wave];   // wave-private: no barrier (kilo_mlp_kernel)
+        {
+            const float4* src = reinterpret_cast<const float4*>(cw + kKiloX3MatFloats);
+            reinterpret_cast<float4*>(sm_job)[lane] = src[lane];
+            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = src[64 + lane];
+        }
+        const float* bias_job = sm_job + kKOffBias + h * 16;
+        const float sb = cw[kKiloX3MatFloats + kKOffSigB], rb0 = cw[kKiloX3MatFloats + kKOffRgbB],
+                    rb1 = cw[kKiloX3MatFloats + kKOffRgbB + 1], rb2 = cw[kKiloX3MatFloats + kKOffRgbB + 2];
+        auto lds16 = [](const float* p) { return *reinterpret_cast<const f32x16*>(p); };
+
+        const int last = seg_e - 1;   // gather pipeline: kilo_mlp_kernel
+        auto tile_id = [&](int t0) { const int k = t0 + j; return unsigned(perm[unsigned(k < last ? k : last)]); };
+        auto dir_of = [&](unsigned id) { return INDEXED ? unsigned(dir_index[id]) : id; };
+        unsigned id_c = tile_id(first), id_n = tile_id(first + 32), id_nn = tile_id(first + 64);
+        float pc[3], pn[3], dc[3] = {0.f, 0.f, 0.f};
+        unsigned di_n, di_c = dir_of(id_c);   // (di_c: the current tile's table row, TABLE only)
+        {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                pc[a] = pts[id_c * 3u + a];
+                if (!TABLE) dc[a] = dirs[di_c * 3u + a];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pn[a] = pts[id_n * 3u + a];
+            di_n = dir_of(id_n);
+        }
+        for (int t0 = first; t0 < seg_e && t0 < first + 32 * job_tiles; t0 += 32) {
+            const bool valid = t0 + j < seg_e;
+            const unsigned id = id_c;
+            const float px = pc[0], py = pc[1], pz = pc[2], dx = dc[0], dy = dc[1], dz = dc[2];
+            f32x16 e[2];
+            u32x4 xpe[2][2][3], xh[1][2][3], xv[2][2][3];
+            if (TABLE) {   // this tile's direction fragments: the table row of its ray, this lane half's 96 B
+                const u32x4* row = reinterpret_cast<const u32x4*>(dirs) + (size_t(di_c) * 2u + unsigned(h)) * 6u;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) xv[1][s2][t] = row[s2 * 3 + t];
+            }
+            {
+                float dn[3] = {0.f, 0.f, 0.f}, pnn[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    if (!TABLE) dn[a] = dirs[di_n * 3u + a];
+                    pnn[a] = pts[id_nn * 3u + a];
+                }
+                const unsigned di_nn = dir_of(id_nn);
+                const unsigned id_nnn = tile_id(t0 + 96);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pc[a] = pn[a], dc[a] = dn[a], pn[a] = pnn[a];
+                id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_c = di_n, di_n = di_nn;
+            }
+            encode_pe_doubling<10>(px, py, pz, h, e);
+            split_block_x3(sel, e[0], xpe[0]);
+            split_block_x3(sel, e[1], xpe[1]);
+            int again = 0;   // keeps the LDS reads below inside the tile loop (kilo_mlp_kernel)
+            asm volatile("" : "+v"(again));
+            const float* bias_h = bias_job + again;
+            const float* sm = sm_job + again;
+            const u32x4* wlo = wlo_job + again;
+            f32x16 y = relu16(tiny_layer_x3<2>(w, wlo, lds16(bias_h), xpe));                        // pts_linears 0 (network.py:132-138)
+            split_block_x3(sel, y, xh[0]);
+            y = relu16(tiny_layer_x3<1>(w + 4, wlo + 4 * 64, lds16(bias_h + 32), xh));            // pts_linears 1
+            float sigma = dot16(lds16(sm + kKOffSigW + h * 16), y);                                 // sigma_linear (:142-144)
+            split_block_x3(sel, y, xh[0]);
+            y = tiny_layer_x3<1>(w + 6, wlo + 6 * 64, lds16(bias_h + 64), xh);                     // feature_linear (:147-149), no activation
+            split_block_x3(sel, y, xv[0]);
+            if (!TABLE) {
+                encode_pe_doubling<4>(dx, dy, dz, h, e);
+                split_block_x3(sel, e[0], xv[1]);
+            }
+            const f32x16 hv = relu16(tiny_layer_x3<2>(w + 8, wlo + 8 * 64, lds16(bias_h + 96), xv));   // view_linears on cat([feature, dirs]) (:152-156)
+            // rgb_linear (:159-161)
+            float r = dot16(lds16(sm + kKOffRgbW + h * 16), hv), g = dot16(lds16(sm + kKOffRgbW + 32 + h * 16), hv),
+                  b = dot16(lds16(sm + kKOffRgbW + 64 + h * 16), hv);
+            r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
+            if (h == 0 && valid) raw[id] = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
         }
     }
 }
@@ -882,11 +1094,12 @@ NRF_EXPORT int64_t nrf_kilo_forward_workspace_bytes(int64_t n_points, int num_ce
 // `src` (optional): the 12 parameter tensors; the cells the batch routes to (and `done`, if given, does not mark as
 // packed already) are packed from them into `packed` (and `packed_t`, if given) between the routing histogram and the
 // MLP launch.
-static int kilo_forward_impl(bool h2, const KiloSrc* src, const int32_t* done, float* packed_t, const float* packed, int num_cells, const float* aabb_host,
+static int kilo_forward_impl(int kind, const KiloSrc* src, const int32_t* done, float* packed_t, const float* packed, int num_cells, const float* aabb_host,
                              const int* res_host, const float* pts, const float* dirs, const int32_t* dir_index,
                              int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream_,
                              const void* dir_table = nullptr, int64_t n_dirs = 0) {
-    if (n_points < 0 || num_cells <= 0 || n_points > (1LL << 28)) return NRF_ERR_SHAPE;  // 32-bit byte offsets in the kernels
+    if (n_points < 0 || num_cells <= 0 || n_points > (1LL << 28) || kind < 0 || kind > 2) return NRF_ERR_SHAPE;  // 32-bit byte offsets in the kernels
+    if (src && kind != 0) return NRF_ERR_SHAPE;   // packing on the way is the training step's, on fp32 records
     if (n_points == 0) return NRF_OK;
     if (!packed || !aabb_host || !res_host || !pts || !(dirs || dir_table) || !raw || !workspace) return NRF_ERR_NULL;
     if (dir_table && (!dir_index || n_dirs <= 0 || n_dirs > (1LL << 24) || !nrf_aligned16(dir_table))) return NRF_ERR_SHAPE;   // 32-bit row offsets
@@ -921,14 +1134,20 @@ static int kilo_forward_impl(bool h2, const KiloSrc* src, const int32_t* done, f
     const dim3 grid(unsigned(2 * cus));
     if (dir_table) {   // per-ray encodings (nrf_kilo_encode_dirs): `dirs` is not read
         const float* tab = static_cast<const float*>(dir_table);
-        const float* guard = reinterpret_cast<const float*>(static_cast<const char*>(dir_table) + a256(n_dirs * kDirRowDwords * 4));
-        if (h2)
+        const float* guard = reinterpret_cast<const float*>(static_cast<const char*>(dir_table) + dir_guard_offset(n_dirs));
+        if (kind == 2)
+            kilo_mlp_x3_kernel<true, true><<<grid, 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, tab,
+                                                                      dir_index, reinterpret_cast<float4*>(raw));
+        else if (kind == 1)
             kilo_mlp_h2_kernel<true, true><<<grid, 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, tab,
                                                                       dir_index, reinterpret_cast<float4*>(raw), guard);
         else
             kilo_mlp_kernel<true, true><<<grid, 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, tab,
                                                                    dir_index, reinterpret_cast<float4*>(raw));
-    } else if (h2) {   // records from nrf_kilo_pack_weights_fp16x2
+    } else if (kind == 2) {   // records from nrf_kilo_pack_weights_bf16x3
+        if (dir_index) kilo_mlp_x3_kernel<true, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS);
+        else kilo_mlp_x3_kernel<false, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS);
+    } else if (kind == 1) {   // records from nrf_kilo_pack_weights_fp16x2
         if (dir_index) kilo_mlp_h2_kernel<true, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS, nullptr);
         else kilo_mlp_h2_kernel<false, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS, nullptr);
     } else if (dir_index)
@@ -942,7 +1161,7 @@ static int kilo_forward_impl(bool h2, const KiloSrc* src, const int32_t* done, f
 NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float* aabb_host, const int* res_host,
                                 const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
                                 float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream) {
-    return kilo_forward_impl(false, nullptr, nullptr, nullptr, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
+    return kilo_forward_impl(0, nullptr, nullptr, nullptr, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
                              workspace, workspace_bytes, stream);
 }
 
@@ -951,33 +1170,61 @@ NRF_EXPORT int nrf_kilo_forward(const float* packed, int num_cells, const float*
 NRF_EXPORT int nrf_kilo_forward_fp16x2(const float* packed_h2, int num_cells, const float* aabb_host, const int* res_host,
                                        const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
                                        float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream) {
-    return kilo_forward_impl(true, nullptr, nullptr, nullptr, packed_h2, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points,
+    return kilo_forward_impl(1, nullptr, nullptr, nullptr, packed_h2, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points,
                              raw, workspace, workspace_bytes, stream);
 }
 
 NRF_EXPORT int64_t nrf_kilo_dir_table_bytes(int64_t n_dirs) { return n_dirs <= 0 ? NRF_ERR_SHAPE : dir_table_bytes(n_dirs); }
 
-NRF_EXPORT int nrf_kilo_encode_dirs(const float* dirs, int64_t n_dirs, int fp16x2, void* table, nrf_stream_t stream) {
-    if (n_dirs < 0 || n_dirs > (1LL << 24)) return NRF_ERR_SHAPE;
+NRF_EXPORT int nrf_kilo_encode_dirs(const float* dirs, int64_t n_dirs, int kind, void* table, nrf_stream_t stream) {
+    if (n_dirs < 0 || n_dirs > (1LL << 24) || kind < 0 || kind > 2) return NRF_ERR_SHAPE;
     if (n_dirs == 0) return NRF_OK;
     if (!dirs || !table) return NRF_ERR_NULL;
     if (!nrf_aligned16(table)) return NRF_ERR_ALIGN;
     unsigned* tab = static_cast<unsigned*>(table);
-    float* guard = reinterpret_cast<float*>(static_cast<char*>(table) + a256(n_dirs * kDirRowDwords * 4));
+    float* guard = reinterpret_cast<float*>(static_cast<char*>(table) + dir_guard_offset(n_dirs));
     const dim3 grid(unsigned((n_dirs + 127) / 128));
     nrf_launch_begin();
-    if (fp16x2) kilo_dir_table_kernel<true><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(dirs, n_dirs, tab, guard);
-    else kilo_dir_table_kernel<false><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(dirs, n_dirs, tab, guard);
+    if (kind == 2) kilo_dir_table_kernel<2><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(dirs, n_dirs, tab, guard);
+    else if (kind == 1) kilo_dir_table_kernel<1><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(dirs, n_dirs, tab, guard);
+    else kilo_dir_table_kernel<0><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(dirs, n_dirs, tab, guard);
     return nrf_launch_status();
 }
 
-NRF_EXPORT int nrf_kilo_forward_encoded(const float* packed, int fp16x2, int num_cells, const float* aabb_host, const int* res_host,
+NRF_EXPORT int nrf_kilo_forward_encoded(const float* packed, int kind, int num_cells, const float* aabb_host, const int* res_host,
                                         const float* pts, const void* dir_table, int64_t n_dirs, const int32_t* dir_index,
                                         int64_t n_points, float* raw, void* workspace, int64_t workspace_bytes,
                                         nrf_stream_t stream) {
     if (!dir_table || !dir_index) return NRF_ERR_NULL;
-    return kilo_forward_impl(fp16x2 != 0, nullptr, nullptr, nullptr, packed, num_cells, aabb_host, res_host, pts, nullptr, dir_index,
+    return kilo_forward_impl(kind, nullptr, nullptr, nullptr, packed, num_cells, aabb_host, res_host, pts, nullptr, dir_index,
                              n_points, raw, workspace, workspace_bytes, stream, dir_table, n_dirs);
+}
+
+// The tiny MLPs at fp32 accuracy on the bf16 matrix cores (three bf16 terms per operand, six MFMAs per product):
+// packed_x3 from nrf_kilo_pack_weights_bf16x3 (nrf_kilo_packed_bf16x3_floats(num_cells) floats).
+NRF_EXPORT int64_t nrf_kilo_packed_bf16x3_floats(int num_cells) {
+    return num_cells <= 0 ? NRF_ERR_SHAPE : int64_t(num_cells) * kKiloCellFloatsX3;
+}
+
+NRF_EXPORT int nrf_kilo_pack_weights_bf16x3(const float* const* tensors, int num_cells, float* packed_x3, nrf_stream_t stream) {
+    if (!tensors || !packed_x3) return NRF_ERR_NULL;
+    if (num_cells <= 0) return NRF_ERR_SHAPE;
+    KiloSrc s;
+    for (int i = 0; i < 12; ++i) {
+        if (!tensors[i]) return NRF_ERR_NULL;
+        s.t[i] = tensors[i];
+    }
+    if (!nrf_aligned16(packed_x3)) return NRF_ERR_ALIGN;
+    nrf_launch_begin();
+    kilo_pack_x3_kernel<<<dim3(unsigned(num_cells)), 256, 0, static_cast<hipStream_t>(stream)>>>(s, num_cells, packed_x3);
+    return nrf_launch_status();
+}
+
+NRF_EXPORT int nrf_kilo_forward_bf16x3(const float* packed_x3, int num_cells, const float* aabb_host, const int* res_host,
+                                       const float* pts, const float* dirs, const int32_t* dir_index, int64_t n_points,
+                                       float* raw, void* workspace, int64_t workspace_bytes, nrf_stream_t stream) {
+    return kilo_forward_impl(2, nullptr, nullptr, nullptr, packed_x3, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points,
+                             raw, workspace, workspace_bytes, stream);
 }
 
 NRF_EXPORT int nrf_kilo_pack_weights_fp16x2(const float* const* tensors, int num_cells, float* packed_h2, nrf_stream_t stream) {
@@ -1005,7 +1252,7 @@ NRF_EXPORT int nrf_kilo_forward_packing(const float* const* tensors, const int32
         if (!tensors[i]) return NRF_ERR_NULL;
         s.t[i] = tensors[i];
     }
-    return kilo_forward_impl(false, &s, packed_cells, packed_t, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
+    return kilo_forward_impl(0, &s, packed_cells, packed_t, packed, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points, raw,
                              workspace, workspace_bytes, stream);
 }
 

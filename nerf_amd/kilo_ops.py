@@ -30,12 +30,16 @@ def _grid_args(aabb, res):
     return aabb, res, aabb.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p)
 
 
+KILO_KINDS = {"fp32": 0, "fp16x2": 1, "bf16x3": 2}   # the C ABI's `kind` argument (include/nerf_amd.h)
+
+
 def kilo_pack_weights(tensors, out: torch.Tensor | None = None, kind: str = "fp32") -> torch.Tensor:
     """12 batched (cells, ...) tensors in KILO_TENSORS order -> per-cell MFMA streaming layout.  ``kind`` "fp16x2": the
-    records of nrf_kilo_forward_fp16x2 (same size; every matrix weight as two fp16 terms)."""
+    records of nrf_kilo_forward_fp16x2 (same size; every matrix weight as two fp16 terms); "bf16x3": the records of
+    nrf_kilo_forward_bf16x3 (every matrix weight as three bf16 terms = exactly its fp32 value; 1.5x the size)."""
     assert len(tensors) == 12
-    if kind not in ("fp32", "fp16x2"):
-        raise ValueError(f"kind {kind!r}: expected 'fp32' or 'fp16x2'")
+    if kind not in KILO_KINDS:
+        raise ValueError(f"kind {kind!r}: expected one of {sorted(KILO_KINDS)}")
     ts = [_f32(t.detach(), "kilo tensor") for t in tensors]
     num_cells = ts[0].shape[0]
     for t, (name, shape, _) in zip(ts, KILO_TENSORS):
@@ -43,13 +47,14 @@ def kilo_pack_weights(tensors, out: torch.Tensor | None = None, kind: str = "fp3
             raise NrfError(f"{name}: shape {tuple(t.shape)}, want {(num_cells,) + shape} "
                            "(only D=2, W=32 cells with 10/4-frequency encodings are supported)")
     dev = ts[0].device
-    n = int(lib().nrf_kilo_packed_floats(num_cells))
-    if out is None:
+    L = lib()
+    n = int((L.nrf_kilo_packed_bf16x3_floats if kind == "bf16x3" else L.nrf_kilo_packed_floats)(num_cells))
+    if out is None or out.numel() != n:
         out = torch.empty(n, dtype=torch.float32, device=dev)
     ptrs = (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
     with torch.cuda.device(dev):
-        fn = lib().nrf_kilo_pack_weights if kind == "fp32" else lib().nrf_kilo_pack_weights_fp16x2
-        check(fn(ptrs, num_cells, _ptr(out), _stream(out)), "nrf_kilo_pack_weights" + ("" if kind == "fp32" else "_fp16x2"))
+        fn = {"fp32": L.nrf_kilo_pack_weights, "fp16x2": L.nrf_kilo_pack_weights_fp16x2, "bf16x3": L.nrf_kilo_pack_weights_bf16x3}[kind]
+        check(fn(ptrs, num_cells, _ptr(out), _stream(out)), "nrf_kilo_pack_weights" + ("" if kind == "fp32" else "_" + kind))
     return out
 
 
@@ -120,7 +125,7 @@ def kilo_encode_dirs(dirs, kind: str = "fp32", out: torch.Tensor | None = None) 
     if out is None or out.numel() < need:
         out = torch.empty(max(need, 256), dtype=torch.uint8, device=dirs.device)
     with torch.cuda.device(dirs.device):
-        check(lib().nrf_kilo_encode_dirs(_ptr(dirs), m, int(kind == "fp16x2"), _ptr(out), _stream(dirs)), "nrf_kilo_encode_dirs")
+        check(lib().nrf_kilo_encode_dirs(_ptr(dirs), m, KILO_KINDS[kind], _ptr(out), _stream(dirs)), "nrf_kilo_encode_dirs")
     return out
 
 
@@ -132,7 +137,8 @@ def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, w
     tiny-MLP kernel reads them from a table (nrf_kilo_encode_dirs + nrf_kilo_forward_encoded: bit-identical raw);
     ``encode_dirs_per_ray=False`` keeps the per-point evaluation (nrf_kilo_forward / _fp16x2).
     ``kind`` "fp16x2": ``packed`` from kilo_pack_weights(kind="fp16x2"), the tiny MLPs on the fp16 matrix cores
-    (fp32-class; operands beyond fp16's range give NaN).
+    (fp32-class; operands beyond fp16's range give NaN); "bf16x3": kilo_pack_weights(kind="bf16x3"), the tiny MLPs on the
+    bf16 matrix cores with every operand as three bf16 terms (fp32's 24 bits and range, six MFMAs per product).
     ``return_workspace``: also return the workspace (the points' order by cell), which kilo_backward needs.
     ``pack_from``: the 12 parameter tensors (or a ParamPointers); the cells this batch routes to are packed from them
     into ``packed`` (and ``packed_t``) on the way (nrf_kilo_forward_packing), except those ``packed_cells`` (int32 per
@@ -152,7 +158,7 @@ def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, w
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=pts.device)
     with torch.cuda.device(pts.device):
-        if kind not in ("fp32", "fp16x2") or (kind != "fp32" and pack_from is not None):
+        if kind not in KILO_KINDS or (kind != "fp32" and pack_from is not None):
             raise NrfError(f"kilo_forward: kind {kind!r} (packing on the way is fp32 only)")
         if pack_from is not None:
             pp = _param_pointers(pack_from)
@@ -170,13 +176,14 @@ def kilo_forward(packed, num_cells: int, aabb, res, pts, dirs, dir_index=None, w
                                                  _stream(pts)), "nrf_kilo_forward_packing")
         elif dir_index is not None and encode_dirs_per_ray and n > 0 and dirs.shape[0] <= (1 << 24):
             table = kilo_encode_dirs(dirs, kind)
-            check(lib().nrf_kilo_forward_encoded(_ptr(packed), int(kind == "fp16x2"), num_cells, pa, pr, _ptr(pts), _ptr(table),
+            check(lib().nrf_kilo_forward_encoded(_ptr(packed), KILO_KINDS[kind], num_cells, pa, pr, _ptr(pts), _ptr(table),
                                                  dirs.shape[0], _ptr(dir_index), n, _ptr(raw), _ptr(workspace),
                                                  workspace.numel(), _stream(pts)), "nrf_kilo_forward_encoded")
         else:
-            fn = lib().nrf_kilo_forward if kind == "fp32" else lib().nrf_kilo_forward_fp16x2
+            L = lib()
+            fn = {"fp32": L.nrf_kilo_forward, "fp16x2": L.nrf_kilo_forward_fp16x2, "bf16x3": L.nrf_kilo_forward_bf16x3}[kind]
             check(fn(_ptr(packed), num_cells, pa, pr, _ptr(pts), _ptr(dirs), _ptr(dir_index), n,
-                     _ptr(raw), _ptr(workspace), workspace.numel(), _stream(pts)), "nrf_kilo_forward")
+                     _ptr(raw), _ptr(workspace), workspace.numel(), _stream(pts)), "nrf_kilo_forward" + ("" if kind == "fp32" else "_" + kind))
     return (raw, workspace) if return_workspace else raw
 
 

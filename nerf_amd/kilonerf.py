@@ -83,8 +83,9 @@ class KiloNetwork(nn.Module):
         self.model = BatchedKiloNeRF(self.num_models)
         self._packed = None
         self._packed_key = None
-        # "fp32" (the reference's arithmetic on the fp32 MFMA) or "fp16x2" (fp32-class on the fp16 MFMA: every operand
-        # as two fp16 terms; inference -- the training kernels read the fp32 records)
+        # "fp32" (the reference's arithmetic on the fp32 MFMA), "bf16x3" (the same 24-bit operands as three bf16 terms each
+        # on the bf16 MFMA) or "fp16x2" (fp32-class on the fp16 MFMA: every operand as two fp16 terms); the last two are
+        # inference forms -- the training kernels read the fp32 records
         self.mlp_dtype = "fp32"
 
     def grid(self):
@@ -154,8 +155,8 @@ class KiloNetView:
 
     @mlp_dtype.setter
     def mlp_dtype(self, kind: str):
-        if kind not in ("fp32", "fp16x2"):
-            raise kilo_ops.NrfError(f"mlp_dtype {kind!r}: expected 'fp32' or 'fp16x2'")
+        if kind not in kilo_ops.KILO_KINDS:
+            raise kilo_ops.NrfError(f"mlp_dtype {kind!r}: expected one of {sorted(kilo_ops.KILO_KINDS)}")
         if hasattr(self.net, "mlp_dtype"):
             self.net.mlp_dtype = kind
         self._mlp_dtype = kind
@@ -246,7 +247,8 @@ class KiloRenderer(nn.Module):
     it in ``__init__``, volumn_renderer.py:36-44; here it is handed in or set later with ``set_occ_grid``)."""
 
     def __init__(self, net: KiloNetwork, cfg=None, occ_grid: torch.Tensor | None = None, mlp_dtype: str | None = None):
-        """``mlp_dtype``: "fp32" (default) or "fp16x2" -- inference with the tiny MLPs on the fp16 matrix cores
+        """``mlp_dtype``: "fp32" (default), "bf16x3" -- inference with the tiny MLPs on the bf16 matrix cores, every operand
+        as three bf16 terms (nrf_kilo_forward_bf16x3: fp32's 24 bits and range) -- or "fp16x2" -- on the fp16 matrix cores
         (nrf_kilo_forward_fp16x2: fp32-class, operands must lie in fp16's range); training always reads fp32 records."""
         super().__init__()
         self.net = net

@@ -103,7 +103,8 @@ def test_full_size_resampling_invariants(frame, dev):
     assert torch.allclose(z2.double().sum(1), bins.double().sum() + fine.double().sum(1), rtol=0, atol=1e-9)
 
 
-def test_kilonerf_full_frame_slices(dev):
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3"])
+def test_kilonerf_full_frame_slices(dev, mlp_dtype):
     from nerf_amd import ops
     from nerf_amd.camera import focal_from_angle, test_set_poses
     from nerf_amd.kilonerf import KiloNetwork, KiloRenderer, default_kilo_cfg
@@ -113,7 +114,7 @@ def test_kilonerf_full_frame_slices(dev):
                         strict=False)
     c = (torch.arange(256, device=dev, dtype=torch.float32) + 0.5) / 256 * 2 - 1
     occ = ((c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2).sqrt() < 0.75).to(torch.uint8)
-    r = KiloRenderer(net.to(dev), default_kilo_cfg(), occ)
+    r = KiloRenderer(net.to(dev), default_kilo_cfg(), occ, mlp_dtype=mlp_dtype)
     o, d = ops.raygen(test_set_poses(200)[11], H, W, focal_from_angle(W), dev)
     whole = r({"xyz": o[None], "viewdirs": d[None]}, is_training=False)
     n_whole = r.last_num_samples
@@ -130,6 +131,12 @@ def test_kilonerf_full_frame_slices(dev):
         for k in ("rgb_map", "depth_map", "alpha_map"):
             assert torch.equal(part[k][0], whole[k][0, sl]), k
     assert total == n_whole
+    if mlp_dtype == "bf16x3":   # the three-term bf16 tiny MLPs against the fp32 MFMA ones on the same 640,000 rays
+        ref = KiloRenderer(net, default_kilo_cfg(), occ, mlp_dtype="fp32")({"xyz": o[None], "viewdirs": d[None]}, is_training=False)
+        for k, tol in (("rgb_map", 2e-5), ("alpha_map", 2e-5), ("depth_map", 1e-4)):
+            err = float((whole[k] - ref[k]).abs().max())
+            print(f"KiloNeRF frame, bf16x3 vs fp32 tiny MLPs, {k}: {err:.2e}")
+            assert err < tol, (k, err)
 
 
 def test_sharded_view_slices_reassemble(frame, dev):

@@ -29,10 +29,10 @@ def _sd(seed=7, gain=20.0, bias=1.0):
     return make_kilo_state_dict_arrays(seed, 4096, gain, bias)
 
 
-@pytest.fixture(scope="module", params=["fp32", "fp16x2"])
+@pytest.fixture(scope="module", params=["fp32", "fp16x2", "bf16x3"])
 def packed(dev, request):
-    """(records, kind): the fp32 MFMA records, and the two-fp16-term records of nrf_kilo_forward_fp16x2 -- one set of
-    tests and one set of bars for both kernels."""
+    """(records, kind): the fp32 MFMA records, the two-fp16-term records of nrf_kilo_forward_fp16x2 and the three-bf16-term
+    records of nrf_kilo_forward_bf16x3 -- one set of tests and one set of bars for the three kernels."""
     from nerf_amd import kilo_ops
     return kilo_ops.kilo_pack_state_dict(_sd(), dev, kind=request.param), request.param
 
@@ -170,6 +170,33 @@ def test_tiny_mlp_fp16x2_range_guard(dev):
     assert bool(in_cell[7]) and torch.isnan(out[in_cell]).all() and torch.equal(out[~in_cell], clean[~in_cell])
 
 
+def test_tiny_mlp_bf16x3_has_fp32_range_and_accuracy(dev):
+    """The three-term bf16 kernel is the fp32 kernel's arithmetic: the inputs that make the fp16x2 kernel answer NaN (a
+    coordinate of 1e5, a weight of 7e4) give finite values within the fp32 kernel's own distance from float64, and on
+    ordinary inputs its distance from float64 is no larger than 1.5x the fp32 MFMA kernel's."""
+    from nerf_amd import kilo_ops
+    from oracle import kilo_oracle as K
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-1, 1, size=(4096, 3)).astype(np.float32)
+    dirs = rng.normal(size=(4096, 3)).astype(np.float32)
+    sd = _sd()
+    cell = int(kilo_ops.kilo_route(_t(pts, dev), AABB, RES)[7])
+    big = {k: v.copy() for k, v in sd.items()}
+    big["model.pts_linears_weights.1"][cell, 3, 5] = 7.0e4
+    far = pts.copy()
+    far[100, 1] = 1.0e5
+    for state, p in ((sd, pts), (big, pts), (sd, far)):
+        out = {k: kilo_ops.kilo_forward(kilo_ops.kilo_pack_state_dict(state, dev, kind=k), 4096, AABB, RES, _t(p, dev),
+                                        _t(dirs, dev), kind=k).cpu().numpy() for k in ("fp32", "bf16x3")}
+        f64 = K.network_forward(state, torch.from_numpy(p), torch.from_numpy(dirs), AABB[:3], AABB[3:], RES,
+                                dtype=torch.float64).numpy()
+        assert np.isfinite(out["bf16x3"]).all()
+        scale = np.maximum(np.abs(f64), 1.0)
+        e32, ex3 = float((np.abs(out["fp32"] - f64) / scale).max()), float((np.abs(out["bf16x3"] - f64) / scale).max())
+        print("relative distance from float64: fp32 kernel %.2e, bf16x3 kernel %.2e" % (e32, ex3))
+        assert ex3 <= max(1.5 * e32, 1e-6), (e32, ex3)
+
+
 def _sphere_occ(n, radius=0.75):
     c = (np.arange(n) + 0.5) / n * 2 - 1
     x, y, z = np.meshgrid(c, c, c, indexing="ij")
@@ -255,7 +282,7 @@ def test_composite_packed_vs_oracle(dev, ert, white):
     assert np.abs(depth.cpu().numpy() - r_depth).max() < 1e-4 * 6
 
 
-@pytest.mark.parametrize("mlp_dtype", ["fp32", "fp16x2"])
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "fp16x2", "bf16x3"])
 def test_kilo_renderer_vs_oracle(dev, mlp_dtype):
     """KiloRenderer(net)(batch) end to end (march -> route/sort -> tiny MLPs -> packed composite) against the
     oracle's render on a 24x24 view of the sphere grid; un-normalised camera directions as the reference passes."""

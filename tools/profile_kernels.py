@@ -20,7 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--train-dtype", default="fp16x2", choices=["fp32", "bf16x3", "fp16x2"], help="--only train: TrainStep's forward_dtype")
-ap.add_argument("--kilo-dtype", default="fp16x2", choices=["fp32", "fp16x2"], help="--only kilo: KiloRenderer's mlp_dtype")
+ap.add_argument("--kilo-dtype", default="fp16x2", choices=["fp32", "fp16x2", "bf16x3"], help="--only kilo: KiloRenderer's mlp_dtype")
 ap.add_argument("--only", default="all", choices=["all", "mlp", "composite", "sample", "bf16", "bf16x3", "fp16x2", "kilo", "train"])
 a = ap.parse_args()
 
