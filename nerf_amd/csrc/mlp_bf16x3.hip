@@ -31,18 +31,6 @@ constexpr int64_t kXSmallFloatOff = int64_t(kXStreamSteps) * kXStepBytes / 4;   
 constexpr int kXLdsConstOff = kXRing * kXChunkBytes;                             // 120 KiB
 constexpr int kXLdsBytes = kXLdsConstOff + kSmallFloats * 4;                     // + 12.1 KiB
 
-// a 32-row block held as 16 accumulator registers -> the B fragments [k16-step][term] of its three terms
-__device__ __forceinline__ void split_tile(const f32x16& v, u32x4 (&out)[2][3]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned p0, p1, p2;
-            split_pair(v[8 * s + 2 * i], v[8 * s + 2 * i + 1], p0, p1, p2);
-            out[s][0][i] = p0, out[s][1][i] = p1, out[s][2][i] = p2;
-        }
-}
-
 // ---- weight packing ------------------------------------------------------------------------
 __device__ __forceinline__ unsigned short bf_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float bf_val(unsigned short b) { return __uint_as_float(unsigned(b) << 16); }
@@ -134,6 +122,7 @@ struct OpIn : OpInBase {
     // in-order MFMA issue for 60 cycles: the matrix pipe runs dry behind them)
     float sa, sb, ra, rb;
     unsigned p0, p1;
+    SplitSel k;   // the residuals by v_dot2c_f32_bf16 (split3.h): 3 + 3 + 3 instructions per pair behind the activation
     template <int MODE>
     __device__ __forceinline__ void input(const f32x16& y, int blk, int q, float& a, float& b) {
         if (MODE == kOpBwd) {
@@ -153,12 +142,20 @@ struct OpIn : OpInBase {
             input<MODE>(y, blk, q, sa, sb);
             p0 = pk_bf16(sa, sb);
             x[q / 4][0][q % 4] = p0;
+        } else if (MODE == kOpBwd) {   // the backward chain keeps the shift / mask / subtract form: measured 1.5 % faster there
+            if (phase == 1) {          // (tools/debug/lib_ab_prof.sh, one box: chain 5.70 against 5.78 ms per step)
+                ra = __fsub_rn(sa, bf_lo(p0)), rb = __fsub_rn(sb, bf_hi(p0));
+                p1 = pk_bf16(ra, rb);
+                x[q / 4][1][q % 4] = p1;
+            } else {
+                x[q / 4][2][q % 4] = pk_bf16(__fsub_rn(ra, bf_lo(p1)), __fsub_rn(rb, bf_hi(p1)));
+            }
         } else if (phase == 1) {
-            ra = __fsub_rn(sa, bf_lo(p0)), rb = __fsub_rn(sb, bf_hi(p0));
+            ra = minus_bf(sa, p0, k.lo), rb = minus_bf(sb, p0, k.hi);
             p1 = pk_bf16(ra, rb);
             x[q / 4][1][q % 4] = p1;
         } else {
-            x[q / 4][2][q % 4] = pk_bf16(__fsub_rn(ra, bf_lo(p1)), __fsub_rn(rb, bf_hi(p1)));
+            x[q / 4][2][q % 4] = pk_bf16(minus_bf(ra, p1, k.lo), minus_bf(rb, p1, k.hi));
         }
     }
     template <int MODE>
@@ -166,7 +163,8 @@ struct OpIn : OpInBase {
         float a, b;
         input<MODE>(y, blk, q, a, b);
         unsigned p0, p1, p2;
-        split_pair(a, b, p0, p1, p2);
+        if (MODE == kOpBwd) split_pair(a, b, p0, p1, p2);
+        else split_pair_dot2(k, a, b, p0, p1, p2);
         x[q / 4][0][q % 4] = p0, x[q / 4][1][q % 4] = p1, x[q / 4][2][q % 4] = p2;
     }
 };
@@ -297,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
 
     XRing st;
     xr_start(st, packed, smem, wave, lane);
+    const SplitSel sel = SplitSel::make();
 
     for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
         const int64_t tile = tg * 4 + wave;
@@ -340,14 +339,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
                 store_block(arow + kActPe * 32, 1, e1);
                 store_block(arow + kActDpe * 32, 0, ed);
             }
-            split_tile(e0, pe[0]);
-            split_tile(e1, pe[1]);
-            split_tile(ed, dpe[0]);
+            split_block_x3(sel, e0, pe[0]);
+            split_block_x3(sel, e1, pe[1]);
+            split_block_x3(sel, ed, dpe[0]);
         }
 
         u32x4 X[8][2][3];
         f32x16 Y[8], Z;
-        OpIn op{op_in(kActRelu, cst + (kOffAlphaW - kOffBias) + h * 16), 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        OpIn op{op_in(kActRelu, cst + (kOffAlphaW - kOffBias) + h * 16), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
         // pts_linears.0 .. 7 and feature_linear (li = 8) as ONE hidden-layer body in a run-time loop; the encoding-only
         // layer runs before li = 1 (pts_linears.0) and before li = 6 (the PE columns of the skip layer pts_linears.5,
         // network.py:58 cat([pe, h]), accumulated onto its hidden part)
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
         float sigma = op.sigma;
         asm volatile("" : "+v"(sigma));   // keep the head where it is (see mlp_bf16.hip)
         // feature -> views: no activation (saved as it is, no mask)
-        OpIn op_views{op_in(kActNone, nullptr, SAVE ? arow + kActFeat * 32 : nullptr), 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        OpIn op_views{op_in(kActNone, nullptr, SAVE ? arow + kActFeat * 32 : nullptr), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
         x3_hidden_layer<4, 1, SAVE ? kOpFwdSave : kOpFwd>(st, lane, bias_h + 9 * 256, X, dpe, Y, Z, op_views);        // views_linears.0
         float r = 0.f, g = 0.f, b = 0.f;
         {
@@ -420,6 +419,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_x3_kernel(const float* __res
 
     XRing st;
     xr_start(st, packed_t, smem, wave, lane, kXBwdChunks);
+    const SplitSel sel = SplitSel::make();
 
     for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
         const int64_t tile = tg * 4 + wave;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_x3_kernel(const float* __res
         }
         // d feature = W_views[:, :256]^T . dYv: four k-blocks in (masked above: all-ones mask here; the split stores them
         // as the dY rows of views_linears.0), eight blocks out
-        OpIn op{op_in(kActNone, aw, drow + kDyV * 32), 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+        OpIn op{op_in(kActNone, aw, drow + kDyV * 32), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
 #pragma unroll
         for (int w = 0; w < 4; ++w) op.m[w] = ~0u;
         x3_hidden_layer<8, 0, kOpBwd, 4>(st, lane, nullptr, X, nullptr, Y, Z, op);

@@ -44,7 +44,7 @@ struct SplitSel {
     unsigned lo, hi;   // {-1, 0}, {0, -1} as bf16 pairs
     static __device__ __forceinline__ SplitSel make() {
         SplitSel s{0x0000BF80u, 0xBF800000u};
-        asm volatile("" : "+v"(s.lo), "+v"(s.hi));
+        asm volatile("" : "+s"(s.lo), "+s"(s.hi));   // scalar registers: the instruction takes one as src0
         return s;
     }
 };
