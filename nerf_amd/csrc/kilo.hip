@@ -277,6 +277,25 @@ __device__ __forceinline__ float dot16(const f32x16& w, const f32x16& x) {
     return acc[0] + acc[1];
 }
 
+// Jobs come off a counter (the workspace's hist[ncell], zero since the memset that precedes the routing), not round-robin:
+// jobs are 1 .. job_tiles tiles long and a static deal left the waves resident for 84 % of the launch.  A wave holds the
+// number of its next job already (the ticket was drawn a job earlier) and looks that job's cell up -- a scalar binary
+// search, a dozen dependent loads -- while the current job's record is on its way; the results do not depend on who
+// evaluates a point, so raw stays bit-identical.
+__device__ __forceinline__ int job_ticket(int* counter, int lane) {   // the number is in lane 0
+    int t = 0;
+    if (lane == 0) t = atomicAdd(counter, 1);
+    return t;
+}
+__device__ __forceinline__ int job_cell_of(const int* __restrict__ job_prefix, int ncell, int job) {   // last c with job_prefix[c] <= job
+    int lo = 0, hi = ncell;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (job_prefix[mid] <= job) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // Persistent waves over jobs; job = up to kJobTiles 32-point tiles of one cell's sorted segment.
 //
 // What bounds it (measured): on gfx950 the f32 MFMA runs at the vector-ALU rate (64 cycles per
@@ -297,22 +316,16 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
                                                           const int* __restrict__ job_prefix,
                                                           const int* __restrict__ perm, const float* __restrict__ pts,
                                                           const float* __restrict__ dirs,
-                                                          const int* __restrict__ dir_index, float4* __restrict__ raw) {
+                                                          const int* __restrict__ dir_index, float4* __restrict__ raw, int* __restrict__ job_counter) {
     __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
-    const int wave_global = blockIdx.x * 4 + wave;
-    const int n_waves = gridDim.x * 4;
     const int total_jobs = job_prefix[ncell];
-    for (int job = wave_global; job < total_jobs; job += n_waves) {
-        // cell of this job: last c with job_prefix[c] <= job
-        int lo = 0, hi = ncell;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (job_prefix[mid] <= job) lo = mid; else hi = mid;
-        }
-        const int cell = lo;
+    int job = __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane));
+    int ticket = job_ticket(job_counter, lane);   // the job after this one
+    int cell = job < total_jobs ? job_cell_of(job_prefix, ncell, job) : 0;
+    for (int job_n = 0, cell_n = 0; job < total_jobs; job = job_n, cell = cell_n) {
         const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
         const int first = seg_b + (job - job_prefix[cell]) * 32 * job_tiles;
         const float* cw = packed + int64_t(cell) * kKiloCellFloats;
@@ -325,8 +338,13 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
         float* sm_job = s_small[wave];
         {
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloSteps * 256);
-            reinterpret_cast<float4*>(sm_job)[lane] = src[lane];
-            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = src[64 + lane];
+            const float4 s0 = src[lane], s1 = src[lane < kKiloSmall / 4 - 64 ? 64 + lane : lane];
+            // every load of this job's record is issued: the next job (its ticket was drawn a job ago) gets its cell now
+            job_n = __builtin_amdgcn_readfirstlane(ticket);
+            ticket = job_ticket(job_counter, lane);
+            cell_n = job_n < total_jobs ? job_cell_of(job_prefix, ncell, job_n) : 0;
+            reinterpret_cast<float4*>(sm_job)[lane] = s0;
+            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = s1;
         }
         const float* bias_job = sm_job + kKOffBias + h * 16;
         const float sb = cw[kKiloSteps * 256 + kKOffSigB], rb0 = cw[kKiloSteps * 256 + kKOffRgbB],
@@ -501,21 +519,16 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
                                                              const int* __restrict__ perm, const float* __restrict__ pts,
                                                              const float* __restrict__ dirs,
                                                              const int* __restrict__ dir_index, float4* __restrict__ raw,
-                                                             const float* __restrict__ dir_guard) {
+                                                             int* __restrict__ job_counter, const float* __restrict__ dir_guard) {
     __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
-    const int wave_global = blockIdx.x * 4 + wave;
-    const int n_waves = gridDim.x * 4;
     const int total_jobs = job_prefix[ncell];
-    for (int job = wave_global; job < total_jobs; job += n_waves) {
-        int lo = 0, hi = ncell;   // cell of this job: last c with job_prefix[c] <= job
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (job_prefix[mid] <= job) lo = mid; else hi = mid;
-        }
-        const int cell = lo;
+    int job = __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane));
+    int ticket = job_ticket(job_counter, lane);   // the job after this one
+    int cell = job < total_jobs ? job_cell_of(job_prefix, ncell, job) : 0;
+    for (int job_n = 0, cell_n = 0; job < total_jobs; job = job_n, cell = cell_n) {
         const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
         const int first = seg_b + (job - job_prefix[cell]) * 32 * job_tiles;
         const float* cw = packed + int64_t(cell) * kKiloCellFloats;
@@ -528,8 +541,13 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
         float* sm_job = s_small[wave];   // wave-private: no barrier (kilo_mlp_kernel)
         {
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloSteps * 256);
-            reinterpret_cast<float4*>(sm_job)[lane] = src[lane];
-            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = src[64 + lane];
+            const float4 s0 = src[lane], s1 = src[lane < kKiloSmall / 4 - 64 ? 64 + lane : lane];
+            // every load of this job's record is issued: the next job (its ticket was drawn a job ago) gets its cell now
+            job_n = __builtin_amdgcn_readfirstlane(ticket);
+            ticket = job_ticket(job_counter, lane);
+            cell_n = job_n < total_jobs ? job_cell_of(job_prefix, ncell, job_n) : 0;
+            reinterpret_cast<float4*>(sm_job)[lane] = s0;
+            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = s1;
         }
         const float* bias_job = sm_job + kKOffBias + h * 16;
         const float sb = cw[kKiloSteps * 256 + kKOffSigB], rb0 = cw[kKiloSteps * 256 + kKOffRgbB],
@@ -702,23 +720,18 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
                                                              const int* __restrict__ job_prefix,
                                                              const int* __restrict__ perm, const float* __restrict__ pts,
                                                              const float* __restrict__ dirs,
-                                                             const int* __restrict__ dir_index, float4* __restrict__ raw) {
+                                                             const int* __restrict__ dir_index, float4* __restrict__ raw, int* __restrict__ job_counter) {
     __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
     __shared__ u32x4 s_wlo[4][kKX3Steps][64];
     const SplitSel sel = SplitSel::make();
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
-    const int wave_global = blockIdx.x * 4 + wave;
-    const int n_waves = gridDim.x * 4;
     const int total_jobs = job_prefix[ncell];
-    for (int job = wave_global; job < total_jobs; job += n_waves) {
-        int lo = 0, hi = ncell;   // cell of this job: last c with job_prefix[c] <= job
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (job_prefix[mid] <= job) lo = mid; else hi = mid;
-        }
-        const int cell = lo;
+    int job = __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane));
+    int ticket = job_ticket(job_counter, lane);   // the job after this one
+    int cell = job < total_jobs ? job_cell_of(job_prefix, ncell, job) : 0;
+    for (int job_n = 0, cell_n = 0; job < total_jobs; job = job_n, cell = cell_n) {
         const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
         const int first = seg_b + (job - job_prefix[cell]) * 32 * job_tiles;
         const float* cw = packed + int64_t(cell) * kKiloCellFloatsX3;
@@ -733,8 +746,13 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
         float* sm_job = s_small[wave];   // wave-private: no barrier (kilo_mlp_kernel)
         {
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloX3MatFloats);
-            reinterpret_cast<float4*>(sm_job)[lane] = src[lane];
-            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = src[64 + lane];
+            const float4 s0 = src[lane], s1 = src[lane < kKiloSmall / 4 - 64 ? 64 + lane : lane];
+            // every load of this job's record is issued: the next job (its ticket was drawn a job ago) gets its cell now
+            job_n = __builtin_amdgcn_readfirstlane(ticket);
+            ticket = job_ticket(job_counter, lane);
+            cell_n = job_n < total_jobs ? job_cell_of(job_prefix, ncell, job_n) : 0;
+            reinterpret_cast<float4*>(sm_job)[lane] = s0;
+            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = s1;
         }
         const float* bias_job = sm_job + kKOffBias + h * 16;
         const float sb = cw[kKiloX3MatFloats + kKOffSigB], rb0 = cw[kKiloX3MatFloats + kKOffRgbB],
@@ -1111,6 +1129,7 @@ static int kilo_forward_impl(int kind, const KiloSrc* src, const int32_t* done, 
     const KiloSortWs ws = kilo_sort_ws(workspace, n_points, num_cells);
     int *cell = ws.cell, *perm = ws.perm, *hist = ws.hist, *seg_start = ws.seg_start, *cursor = ws.cursor,
         *job_prefix = ws.job_prefix;
+    int* job_counter = hist + num_cells;   // the spare word behind the histogram: zeroed with it below, the MLP kernels draw their jobs from it
     const Grid g = make_grid(aabb_host, res_host);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1130,20 +1149,20 @@ static int kilo_forward_impl(int kind, const KiloSrc* src, const int32_t* done, 
     }
     kilo_cell_scan_kernel<<<1, 1024, 0, stream>>>(hist, num_cells, job_tiles, seg_start, cursor, job_prefix);
     kilo_scatter_kernel<<<dim3(rb), 256, size_t(num_cells) * 4, stream>>>(cell, n_points, num_cells, cursor, perm);
-#define NRF_KILO_ARGS packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, dirs, dir_index, reinterpret_cast<float4*>(raw)
+#define NRF_KILO_ARGS packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, dirs, dir_index, reinterpret_cast<float4*>(raw), job_counter
     const dim3 grid(unsigned(2 * cus));
     if (dir_table) {   // per-ray encodings (nrf_kilo_encode_dirs): `dirs` is not read
         const float* tab = static_cast<const float*>(dir_table);
         const float* guard = reinterpret_cast<const float*>(static_cast<const char*>(dir_table) + dir_guard_offset(n_dirs));
         if (kind == 2)
             kilo_mlp_x3_kernel<true, true><<<grid, 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, tab,
-                                                                      dir_index, reinterpret_cast<float4*>(raw));
+                                                                      dir_index, reinterpret_cast<float4*>(raw), job_counter);
         else if (kind == 1)
             kilo_mlp_h2_kernel<true, true><<<grid, 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, tab,
-                                                                      dir_index, reinterpret_cast<float4*>(raw), guard);
+                                                                      dir_index, reinterpret_cast<float4*>(raw), job_counter, guard);
         else
             kilo_mlp_kernel<true, true><<<grid, 256, 0, stream>>>(packed, num_cells, job_tiles, seg_start, job_prefix, perm, pts, tab,
-                                                                   dir_index, reinterpret_cast<float4*>(raw));
+                                                                   dir_index, reinterpret_cast<float4*>(raw), job_counter);
     } else if (kind == 2) {   // records from nrf_kilo_pack_weights_bf16x3
         if (dir_index) kilo_mlp_x3_kernel<true, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS);
         else kilo_mlp_x3_kernel<false, false><<<grid, 256, 0, stream>>>(NRF_KILO_ARGS);
