@@ -698,6 +698,19 @@ __global__ __launch_bounds__(256) void kilo_pack_x3_kernel(KiloSrc s, int num_ce
 template <int NKB>
 __device__ __forceinline__ f32x16 tiny_layer_x3(const u32x4 (*w)[2], const u32x4* wlo, f32x16 init, const u32x4 (*x)[2][3]) {
     f32x16 y = init;
+#ifdef KILO_ABL_NOMFMA   // timing-only ablation: the layer without its MFMAs (operands still consumed)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int st = kb * 2 + s2;
+            const u32x4 w2 = wlo[st * 64];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                y[c] += __uint_as_float(w2[c] ^ w[st][0][c] ^ w[st][1][c] ^ x[kb][s2][0][c] ^ x[kb][s2][1][c] ^ x[kb][s2][2][c]);
+        }
+    return y;
+#endif
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -760,7 +773,11 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
         auto lds16 = [](const float* p) { return *reinterpret_cast<const f32x16*>(p); };
 
         const int last = seg_e - 1;   // gather pipeline: kilo_mlp_kernel
+#ifdef KILO_ABL_NOGATHER   // timing-only ablation: points in sorted order (coalesced point loads and raw stores, no perm)
+        auto tile_id = [&](int t0) { const int k = t0 + j; return unsigned(k < last ? k : last); };
+#else
         auto tile_id = [&](int t0) { const int k = t0 + j; return unsigned(perm[unsigned(k < last ? k : last)]); };
+#endif
         auto dir_of = [&](unsigned id) { return INDEXED ? unsigned(dir_index[id]) : id; };
         unsigned id_c = tile_id(first), id_n = tile_id(first + 32), id_nn = tile_id(first + 64);
         float pc[3], pn[3], dc[3] = {0.f, 0.f, 0.f};
@@ -786,7 +803,12 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) xv[1][s2][t] = row[s2 * 3 + t];
+                    for (int t = 0; t < 3; ++t)
+#ifdef KILO_ABL_NOTABLE   // timing-only ablation: no direction rows
+                        xv[1][s2][t] = u32x4{di_c, di_c + t, di_c, unsigned(size_t(row))};
+#else
+                        xv[1][s2][t] = row[s2 * 3 + t];
+#endif
             }
             {
                 float dn[3] = {0.f, 0.f, 0.f}, pnn[3];

@@ -376,16 +376,26 @@ __device__ __forceinline__ f32x16 encode_block(float x, float y, float z, int h)
 // 9.3e-8 for the direct evaluation: below the fp32 accumulation noise of the networks that use it (the KiloNeRF
 // cells, K <= 64) and far below a bf16 ulp.  The 8x256 fp32 chain keeps encode_block: the encoding is 2 % of its time.
 // Exact argument e = 3g + c is coordinate c at octave 2g; the lane halves split the arguments as in encode_block.
-template <int L>
+// (V0, V1: the argument pairs [V0, V1) only -- a caller that spreads the encoding over several MFMA chains takes it in
+// parts, the part with V0 == 0 also fills the raw-input slots; the default is all of it.)
+template <int L, int V0 = 0, int V1 = (3 * (L / 2) + 1) / 2>
 __device__ __forceinline__ void encode_pe_doubling(float x, float y, float z, int h, f32x16* out) {
     static_assert(L % 2 == 0, "octaves are taken in (even, odd) pairs");
     constexpr int NE = 3 * (L / 2);
     constexpr int NB = (3 * L + 2 + 15) / 16;
+    static_assert(0 <= V0 && V0 < V1 && V1 <= (NE + 1) / 2, "argument pairs");
+    if (V0 == 0) {
 #pragma unroll
-    for (int n = 3 * L; n < 16 * NB; ++n)
-        out[n / 16][n % 16] = n == 3 * L ? (h ? y : x) : (n == 3 * L + 1 ? (h ? 0.f : z) : 0.f);
+        for (int n = 3 * L; n < 16 * NB; ++n)
+            out[n / 16][n % 16] = n == 3 * L ? (h ? y : x) : (n == 3 * L + 1 ? (h ? 0.f : z) : 0.f);
+    }
+#ifdef KILO_ABL_NOPE   // timing-only ablation: no trigonometry
 #pragma unroll
-    for (int v = 0; v < (NE + 1) / 2; ++v) {
+    for (int n = 0; n < 3 * L; ++n) out[n / 16][n % 16] = x + float(n);
+    return;
+#endif
+#pragma unroll
+    for (int v = V0; v < V1; ++v) {
         const int e0 = 2 * v, e1 = 2 * v + 1;
         const int c0 = e0 % 3, g0 = e0 / 3, c1 = e1 % 3, g1 = e1 / 3;
         const float a0 = (c0 == 0 ? x : (c0 == 1 ? y : z)) * float(1 << (2 * g0));

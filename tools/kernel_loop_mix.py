@@ -4,7 +4,8 @@
     python tools/kernel_loop_mix.py <kernel-name-substring> [min_mfma_in_loop] [--ops]
 
 Disassembles nerf_amd/lib/libnerf_amd.so, finds for every matching kernel the smallest loop (backward branch) that
-holds at least `min_mfma_in_loop` MFMAs (default 8) and prints its instruction classes; --ops lists the VALU opcodes.
+holds at least `min_mfma_in_loop` MFMAs (default 8) and prints its instruction classes; --ops lists the VALU opcodes,
+--seq prints the number of VALU instructions between consecutive MFMAs (how the two pipes are interleaved).
 This is the static count behind statements like "540 VALU instructions per 32-point tile" in DESIGN.md."""
 import collections
 import os
@@ -20,7 +21,7 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
 def disassembly():
-    blob = open(os.path.join(ROOT, "nerf_amd", "lib", "libnerf_amd.so"), "rb").read()
+    blob = open(os.environ.get("NRF_LIB", os.path.join(ROOT, "nerf_amd", "lib", "libnerf_amd.so")), "rb").read()   # NRF_LIB: another build (A/B variants)
     with tempfile.TemporaryDirectory() as tmp:
         i = 0
         for m in re.finditer(MAGIC, blob):
@@ -93,6 +94,15 @@ def main():
             body = ins[best[0]:best[1] + 1]
             c = collections.Counter(classify(t.split()[0]) for _, t in body)
             print(f"{dem[:100]}\n   loop of {len(body)} instructions: " + "  ".join(f"{k} {v}" for k, v in sorted(c.items(), key=lambda kv: -kv[1])))
+            if "--seq" in sys.argv:   # the loop as a string: M = MFMA, then the count of VALU (and other) instructions up to the next one
+                seq, run = [], 0
+                for _, t in body:
+                    if "mfma" in t:
+                        seq.append(str(run)), seq.append("M")
+                        run = 0
+                    elif t.startswith("v_"):
+                        run += 1
+                print("   " + " ".join(seq + [str(run)]))
             if "--ops" in sys.argv:
                 ops = collections.Counter(t.split()[0].replace("_e32", "").replace("_e64", "") for _, t in body if t.startswith("v_") and "mfma" not in t)
                 print("   " + "  ".join(f"{k} {v}" for k, v in ops.most_common(30)))

@@ -32,7 +32,7 @@ def code_objects(blob):
 
 def main():
     want = sys.argv[1:]
-    blob = open(os.path.join(ROOT, "nerf_amd", "lib", "libnerf_amd.so"), "rb").read()
+    blob = open(os.environ.get("NRF_LIB", os.path.join(ROOT, "nerf_amd", "lib", "libnerf_amd.so")), "rb").read()   # NRF_LIB: another build (A/B variants)
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
         for i, obj in enumerate(code_objects(blob)):
