@@ -35,7 +35,11 @@ constexpr int kXLdsBytes = kXLdsConstOff + kSmallFloats * 4;                    
 __device__ __forceinline__ unsigned short bf_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float bf_val(unsigned short b) { return __uint_as_float(unsigned(b) << 16); }
 
-__global__ void xpack_layer_kernel(XPackLayer p) {   // one thread writes the three terms of one weight
+// all layers of a stream in one launch (blockIdx.y = layer; mlp_fp16x2.hip: hpack_layers_kernel)
+constexpr int kXPackBatch = 11;
+struct XPackBatch { XPackLayer l[kXPackBatch]; };
+__global__ void xpack_layers_kernel(XPackBatch b) {   // one thread writes the three terms of one weight
+    const XPackLayer& p = b.l[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= xpack_total(p)) return;
     int step, lane, jj;
@@ -223,7 +227,7 @@ __device__ __forceinline__ void x3_pe_layer(XRing& st, int lane, const float* bi
 // Hidden-type layer: Y[ob] = bias + W . [X (8 k-blocks), post], X[kb] = op(Y[kb] of the previous layer).
 // Making one X[kb] is 120 VALU instructions, more than the 12 MFMAs of one (block, k-block) can cover, so the layer
 // opens with output blocks 0 AND 1 accumulated together (stream order [kb][ob in {0,1}][s2] for that part, see
-// xpack_layer_kernel): X[kb+1] is made in eight slices under the 24 MFMAs of k-block kb.  Block 1 accumulates into the
+// xpack_layers_kernel): X[kb+1] is made in eight slices under the 24 MFMAs of k-block kb.  Block 1 accumulates into the
 // spare block Z because the previous layer's Y[1] is still needed (it becomes X[1] during k-block 0).
 template <int NOB, int NPOST, int MODE, int NHID = 8>
 __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float* bias_h, u32x4 (*X)[2][3],
@@ -548,15 +552,18 @@ NRF_EXPORT int nrf_pack_weights_transposed_bf16x3(const float* const* w, void* p
     unsigned short* base = static_cast<unsigned short*>(packed_t);
     nrf_launch_begin();
     int step = 0;
+    XPackBatch batch;
+    int n_batch = 0, max_total = 0;
     auto launch = [&](const float* W, int ldw, int in_blocks, int col0) {   // in_blocks = k-blocks = rows of W / 32
-        XPackLayer p{W, base + int64_t(step) * (kXStepBytes / 2), ldw, 8, 0, in_blocks, 0, 0, 0, 0, col0, 0, 2, 1};
+        batch.l[n_batch++] = XPackLayer{W, base + int64_t(step) * (kXStepBytes / 2), ldw, 8, 0, in_blocks, 0, 0, 0, 0, col0, 0, 2, 1};
         const int total = 8 * in_blocks * 2 * 512;
-        xpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+        max_total = total > max_total ? total : max_total;
         step += 8 * in_blocks * 2;
     };
     launch(w[10], 283, 4, 0);   // views^T: 128 outputs of views_linears.0 contracted, 256 feature columns out
     launch(w[8], 256, 8, 0);    // feature^T
     for (int l = 7; l >= 1; --l) launch(w[l], l == 5 ? 319 : 256, 8, l == 5 ? 63 : 0);
+    xpack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch);
     return nrf_launch_status();
 }
 
@@ -571,12 +578,16 @@ NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     unsigned short* base = static_cast<unsigned short*>(packed);
     nrf_launch_begin();
+    XPackBatch batch;
+    int n_batch = 0, max_total = 0;
     auto launch = [&](XPackLayer p, int step0) {
         p.dst = base + int64_t(step0) * (kXStepBytes / 2);
         const int total = p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512;
-        xpack_layer_kernel<<<(total + 255) / 256, 256, 0, stream>>>(p);
+        batch.l[n_batch++] = p;
+        max_total = total > max_total ? total : max_total;
     };
     xpack_forward_layers(w, launch);
+    xpack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch);
     const PackSmall s = xpack_small(w, b, packed, kXSmallFloatOff);
     pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
     return nrf_launch_status();
