@@ -92,6 +92,9 @@ def parse(argv=None):
                          "the bf16 MLP of configs[4], reported under its own metric name.  --mode train runs its matrix work "
                          "on the kernels of the same --dtype (bf16x3, fp32 or fp16x2); --mode kilo runs the tiny MLPs on the "
                          "fp32 MFMA kernel unless --dtype fp16x2")
+    ap.add_argument("--kilo-occ", default="bricks", choices=["bricks", "bytes"],
+                    help="--mode kilo: the march's count pass on the bit-brick copy of the occupancy grid (default, what "
+                         "KiloRenderer does) or on the uint8 grid")
     ap.add_argument("--kilo-dirs", default="per_ray", choices=["per_ray", "per_point"],
                     help="kilo mode: direction encodings once per ray from a table (default) or re-evaluated per point as the "
                          "reference does (A/B switch; bit-identical outputs)")
@@ -386,11 +389,14 @@ def kilo_bench(args, dev, rank, world, dist):
         return e
 
     samples = []
+    # the occupancy grid as bit bricks (built once per grid, as KiloRenderer does); --kilo-occ bytes walks the uint8 grid
+    bricks = r.occ_bricks() if getattr(args, "kilo_occ", "bricks") == "bricks" else None
 
     def step(k, timed):
         rays_o, rays_d = ops.raygen(poses[(k * world + rank) % len(poses)], H, W, focal, dev)
         e0 = E()
-        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(rays_o, rays_d, r.occ_grid, aabb, r.near, r.far, r.step)
+        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(rays_o, rays_d, r.occ_grid, aabb, r.near, r.far, r.step,
+                                                                    bricks=bricks)
         e1 = E()
         raw = kilo_ops.kilo_forward(packed, net.num_models, aabb, res, pts, rays_d, ray_idx, kind=kind,
                                     encode_dirs_per_ray=getattr(args, "kilo_dirs", "per_ray") == "per_ray")

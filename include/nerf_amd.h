@@ -344,6 +344,17 @@ int nrf_kilo_march_count(const float* rays_o, const float* rays_d, int64_t n_ray
                          const int* occ_res_host, const float* aabb_host, float t_near, float t_far, float step,
                          int32_t* counts, int32_t* offsets, int64_t* total, void* workspace, int64_t workspace_bytes,
                          nrf_stream_t stream);
+/* The same pass 1 over a BIT-BRICK copy of the grid (no counterpart in the reference: the grid lives inside nerfacc there,
+ * volumn_renderer.py:47-54): nrf_occ_pack_bricks turns the uint8 grid into one 64-bit word per 4 x 4 x 4 voxels (bit
+ * (x & 3) * 16 + (y & 3) * 4 + (z & 3); nrf_occ_bricks_bytes(res) bytes, 8-byte aligned; 2 MB for 256^3), built once per
+ * grid; a ray's 64-step chunk then touches about ten cache lines instead of forty.  Same counts, offsets, total and masks
+ * as nrf_kilo_march_count on the uint8 grid, bit for bit; pass 2 (nrf_kilo_march_write with that workspace) is unchanged. */
+int64_t nrf_occ_bricks_bytes(const int* occ_res_host);
+int nrf_occ_pack_bricks(const uint8_t* occ, const int* occ_res_host, uint64_t* bricks, nrf_stream_t stream);
+int nrf_kilo_march_count_bricks(const float* rays_o, const float* rays_d, int64_t n_rays, const uint64_t* bricks,
+                                const int* occ_res_host, const float* aabb_host, float t_near, float t_far, float step,
+                                int32_t* counts, int32_t* offsets, int64_t* total, void* workspace,
+                                int64_t workspace_bytes, nrf_stream_t stream);
 int nrf_kilo_march_write(const float* rays_o, const float* rays_d, int64_t n_rays, const uint8_t* occ,
                          const int* occ_res_host, const float* aabb_host, float t_near, float t_far, float step,
                          const int32_t* offsets, float* pts, int32_t* ray_idx, float* t_start, float* t_end,

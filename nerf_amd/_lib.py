@@ -35,6 +35,7 @@ SYMBOLS = (
     "nrf_render_fp16x2", "nrf_mlp_forward_rays_train_fp16x2", "nrf_kilo_pack_weights_fp16x2", "nrf_kilo_forward_fp16x2", "nrf_occ_bake_fp16x2", "nrf_packed_bwd_fp16x2_bytes", "nrf_pack_weights_transposed_fp16x2", "nrf_mlp_backward_fp16x2",
     "nrf_kilo_dir_table_bytes", "nrf_kilo_encode_dirs", "nrf_kilo_forward_encoded",
     "nrf_kilo_packed_bf16x3_floats", "nrf_kilo_pack_weights_bf16x3", "nrf_kilo_forward_bf16x3",
+    "nrf_occ_bricks_bytes", "nrf_occ_pack_bricks", "nrf_kilo_march_count_bricks",
 )
 
 P = C.c_void_p
@@ -209,6 +210,12 @@ def lib() -> C.CDLL:
     L.nrf_kilo_march_workspace_bytes.argtypes = [I64, F, F, F]
     L.nrf_kilo_march_count.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, I64, P]
     L.nrf_kilo_march_write.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, P, P, P, I64, P]
+    L.nrf_occ_bricks_bytes.restype = I64
+    L.nrf_occ_bricks_bytes.argtypes = [P]
+    L.nrf_occ_pack_bricks.argtypes = [P, P, P, P]
+    L.nrf_occ_pack_bricks.restype = INT
+    L.nrf_kilo_march_count_bricks.argtypes = [P, P, I64, P, P, P, F, F, F, P, P, P, P, I64, P]
+    L.nrf_kilo_march_count_bricks.restype = INT
     L.nrf_kilo_composite.argtypes = [P, P, P, P, P, I64, F, INT, P, P, P, P]
     L.nrf_kilo_packed_bwd_floats.restype = I64
     L.nrf_kilo_packed_bwd_floats.argtypes = [INT]

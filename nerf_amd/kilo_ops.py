@@ -307,17 +307,39 @@ def kilo_cells_scatter(records: torch.Tensor, cells: torch.Tensor, tensors) -> N
 _pinned_total = {}
 
 
+def occ_pack_bricks(occ: torch.Tensor) -> torch.Tensor:
+    """The (rx,ry,rz) uint8 grid as bit bricks (one int64 word per 4 x 4 x 4 voxels) for ``kilo_march(..., bricks=)``:
+    built once per grid, 1/8 of a byte per voxel, so the count pass's lookups stay in L2."""
+    if occ.dtype != torch.uint8 or occ.ndim != 3 or not occ.is_cuda:
+        raise NrfError("occ: expected a 3-D uint8 cuda tensor")
+    occ = occ.contiguous()
+    res = np.ascontiguousarray(np.asarray(occ.shape, dtype=np.int32))
+    pr = res.ctypes.data_as(C.c_void_p)
+    need = int(lib().nrf_occ_bricks_bytes(pr))
+    if need < 0:
+        check(need, "nrf_occ_bricks_bytes")
+    bricks = torch.empty(need // 8, dtype=torch.int64, device=occ.device)
+    with torch.cuda.device(occ.device):
+        check(lib().nrf_occ_pack_bricks(_ptr(occ), pr, _ptr(bricks), _stream(occ)), "nrf_occ_pack_bricks")
+    return bricks
+
+
 def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: float, step: float,
-               reuse_masks: bool = True, after_count=None):
+               reuse_masks: bool = True, after_count=None, bricks: torch.Tensor | None = None):
     """Occupancy-grid marching.  Returns (pts (N,3), ray_idx (N,), t_start (N,), t_end (N,),
     offsets (R,), counts (R,)); one host sync to learn N between the count and the write pass.  ``reuse_masks``:
     the write pass takes the kept steps from the count pass's ballots instead of walking the grid again (same bits).
     ``after_count``: called once the count pass and the read-back of N are enqueued and before the host waits for
-    them -- GPU work that does not depend on N goes here and runs while the host wakes up and sizes the buffers."""
+    them -- GPU work that does not depend on N goes here and runs while the host wakes up and sizes the buffers.
+    ``bricks``: ``occ_pack_bricks(occ)``; the count pass then looks the bit bricks up instead of the bytes (same result)."""
     rays_o, rays_d = _f32(rays_o, "rays_o").reshape(-1, 3), _f32(rays_d, "rays_d").reshape(-1, 3)
     if occ.dtype != torch.uint8 or occ.ndim != 3 or not occ.is_cuda:
         raise NrfError("occ: expected a 3-D uint8 cuda tensor")
     occ = occ.contiguous()
+    if bricks is not None and (bricks.dtype != torch.int64 or not bricks.is_cuda or not bricks.is_contiguous()
+                               or bricks.numel() * 8 != int(lib().nrf_occ_bricks_bytes(
+                                   np.ascontiguousarray(np.asarray(occ.shape, dtype=np.int32)).ctypes.data_as(C.c_void_p)))):
+        raise NrfError("bricks: expected occ_pack_bricks(occ) of this grid")
     R = rays_o.shape[0]
     dev = rays_o.device
     _a, _r, pa, pr = _grid_args(aabb, occ.shape)
@@ -333,9 +355,14 @@ def kilo_march(rays_o, rays_d, occ: torch.Tensor, aabb, t_near: float, t_far: fl
         check(need, "nrf_kilo_march_workspace_bytes")
     ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(lib().nrf_kilo_march_count(_ptr(rays_o), _ptr(rays_d), R, _ptr(occ), pr, pa, float(t_near), float(t_far),
-                                         float(step), _ptr(counts), _ptr(offsets), _ptr(total), _ptr(ws), ws.numel(),
-                                         _stream(rays_o)), "nrf_kilo_march_count")
+        if bricks is not None:
+            check(lib().nrf_kilo_march_count_bricks(_ptr(rays_o), _ptr(rays_d), R, _ptr(bricks), pr, pa, float(t_near),
+                                                    float(t_far), float(step), _ptr(counts), _ptr(offsets), _ptr(total),
+                                                    _ptr(ws), ws.numel(), _stream(rays_o)), "nrf_kilo_march_count_bricks")
+        else:
+            check(lib().nrf_kilo_march_count(_ptr(rays_o), _ptr(rays_d), R, _ptr(occ), pr, pa, float(t_near), float(t_far),
+                                             float(step), _ptr(counts), _ptr(offsets), _ptr(total), _ptr(ws), ws.numel(),
+                                             _stream(rays_o)), "nrf_kilo_march_count")
         if after_count is None:
             n = int(total.item())
         else:

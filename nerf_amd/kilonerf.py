@@ -213,7 +213,7 @@ class _KiloRenderFn(torch.autograd.Function):
         net = renderer.view
         aabb, res = net.grid()
         pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, renderer.occ_grid, aabb, renderer.near,
-                                                                    renderer.far, renderer.step)
+                                                                    renderer.far, renderer.step, bricks=renderer.occ_bricks())
         renderer.last_num_samples = int(pts.shape[0])
         if net.mlp_dtype != "fp32":
             raise kilo_ops.NrfError("KiloRenderer: the backward kernels read the fp32 records; train with mlp_dtype='fp32'")
@@ -300,6 +300,17 @@ class KiloRenderer(nn.Module):
             raise ValueError(f"occupancy grid {tuple(occ_grid.shape)} != {self.occ_grid_resolution}")
         self.occ_grid = occ_grid.to(torch.uint8).contiguous()
 
+    def occ_bricks(self):
+        """``kilo_ops.occ_pack_bricks`` of the current grid for the march's count pass, rebuilt when ``occ_grid`` is another
+        tensor or has been written in place (storage address + torch's version counter are the key)."""
+        g = self.occ_grid
+        if g is None or not g.is_cuda:
+            return None
+        key = (g.data_ptr(), g._version, g.device, tuple(g.shape))
+        if getattr(self, "_bricks_key", None) != key:
+            self._bricks, self._bricks_key = kilo_ops.occ_pack_bricks(g), key
+        return self._bricks
+
     def grid_filename(self, occ_threshold) -> str:
         """The reference's cache file name (volumn_renderer.py:37-38)."""
         r = self.occ_grid_resolution
@@ -358,7 +369,8 @@ class KiloRenderer(nn.Module):
     def _render_once(self, o, d):
         aabb, res = self.view.grid()
         occ = self.occ_grid
-        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, occ, aabb, self.near, self.far, self.step)
+        pts, ray_idx, ts, te, offsets, counts = kilo_ops.kilo_march(o, d, occ, aabb, self.near, self.far, self.step,
+                                                                    bricks=self.occ_bricks())
         self.last_num_samples = int(pts.shape[0])
         if pts.shape[0]:
             raw = kilo_ops.kilo_forward(self.view.packed(), self.view.num_models, aabb, res, pts, d, ray_idx,

@@ -249,6 +249,35 @@ def test_march_mask_handover_other_step_sizes(dev, step, box):
             assert np.array_equal(a.cpu().numpy(), b), (nm, reuse)
 
 
+@pytest.mark.parametrize("res,box", [((32, 32, 32), AABB), ((30, 17, 9), [-1.3, -0.9, -1.0, 1.1, 1.2, 0.7])])
+def test_march_on_bit_bricks_is_bit_identical(dev, res, box):
+    """nrf_occ_pack_bricks + nrf_kilo_march_count_bricks: the count pass on one 64-bit word per 4 x 4 x 4 voxels gives the
+    uint8 grid's samples bit for bit -- also for a random (not smooth) grid and edges that are no multiples of four."""
+    from nerf_amd import kilo_ops
+    rng = np.random.default_rng(11)
+    occ = (rng.random(res) < 0.3).astype(np.uint8)
+    o, d = _camera_rays(24, seed=3)
+    g = _t(occ, dev)
+    bricks = kilo_ops.occ_pack_bricks(g)
+    bx, by, bz = [(r + 3) // 4 for r in res]
+    words = bricks.cpu().numpy().view(np.uint64)[:bx * by * bz].reshape(bx, by, bz)
+    pad = np.zeros((bx * 4, by * 4, bz * 4), dtype=np.uint64)
+    pad[:res[0], :res[1], :res[2]] = occ
+    want = np.zeros((bx, by, bz), dtype=np.uint64)
+    for dx in range(4):
+        for dy in range(4):
+            for dz in range(4):
+                want |= pad[dx::4, dy::4, dz::4] << np.uint64(dx * 16 + dy * 4 + dz)
+    assert np.array_equal(words, want)
+    a = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), g, box, 2.0, 6.0, 0.005)
+    b = kilo_ops.kilo_march(_t(o, dev), _t(d, dev), g, box, 2.0, 6.0, 0.005, bricks=bricks)
+    assert int(a[5].sum()) > 0
+    for nm, x, y in zip(["pts", "ray_idx", "t_start", "t_end", "offsets", "counts"], a, b):
+        assert torch.equal(x, y), nm
+    with pytest.raises(kilo_ops.NrfError):
+        kilo_ops.kilo_march(_t(o, dev), _t(d, dev), g, box, 2.0, 6.0, 0.005, bricks=bricks[:-1])
+
+
 def test_march_empty_grid_and_no_rays(dev):
     from nerf_amd import kilo_ops
     o, d = _camera_rays(8)
