@@ -65,7 +65,9 @@ def test_training_step_on_a_side_stream():
         for _ in range(2):
             ts2.step(o2, d2, gt2, u2[0], u2[1], u2[2], u2[3])
     side.synchronize()
-    assert float(ts2.loss) == loss and torch.equal(ts2.flat, want)
+    assert torch.equal(ts2.flat, want)                          # parameters after two steps: bit for bit
+    # (the loss word is summed with one float atomic per wavefront, nrf_mse_grad: the order may differ in the last bit)
+    assert abs(float(ts2.loss) - loss) <= 1e-6 * max(1.0, abs(loss))
 
 
 def test_kilonerf_frame_and_training_step_on_a_side_stream():
