@@ -286,7 +286,6 @@ __device__ __forceinline__ void h2_hidden_layer(HRing& st, int lane, const float
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto bias = [&](int ob) { return MODE == kOpBwd ? zero16 : *reinterpret_cast<const f32x16*>(bias_h + ob * 32); };
     static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
-    op.begin(0, Y[0]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) op.template pair<MODE>(Y[0], X[0], 0, q);
     Y[0] = bias(0);
@@ -296,7 +295,6 @@ __device__ __forceinline__ void h2_hidden_layer(HRing& st, int lane, const float
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         const bool make = kb + 1 < NHID;
-        if (make) op.begin(kb + 1, Y[kb + 1]);
 #pragma unroll
         for (int b = 0; b < LEAD; ++b)
 #pragma unroll
@@ -466,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fp16x2_kernel(const char* __restri
         // network.py:58 cat([pe, h]), accumulated onto its hidden part)
         for (int li = 1; li <= 8; ++li) {
             if (li == 1 || li == 6) h2_pe_layer(st, lane, bias_h, li == 6, pe, Y, YL);
-            op.alpha = li == 8;                                       // feature_linear's input relu(h7) feeds alpha_linear
+            if (li == 8) op.alpha_head(Y);                            // feature_linear's input relu(h7) feeds alpha_linear
             if (SAVE) {   // the layer's input h_{li-1} = relu(Y) and its signs (mask li - 1)
                 op.save = arow + (kActH + (li - 1) * 256) * 32;
                 op.msave = mrow + (li - 1) * 4 * 64;

@@ -92,7 +92,6 @@ constexpr int kOpFwd = 0, kOpFwdSave = 1, kOpBwd = 2;   // input-op modes
 // (feature_linear) also feeds alpha_linear (256 -> 1, fp32 weights, VALU).
 struct OpInBase {
     int lim;
-    bool alpha;        // run-time, uniform
     const float* aw;   // cst + alpha weights + h * 16
     float sigma;
     // training forward (kOpFwdSave): the activated input of the layer goes to `save` (acts rows of this layer's input,
@@ -130,10 +129,16 @@ struct OpInBase {
             }
         }
     }
-    __device__ __forceinline__ void begin(int kb, const f32x16& y) {
-        if (alpha) {
+    // alpha_linear (network.py:61) on relu(h7): Y holds layer 7's raw outputs when the loop reaches feature_linear.  ONE
+    // lump per tile, in front of that layer -- as a run-time `if (alpha)` inside the shared layer body (once per k-block)
+    // the compiler gave EVERY layer's k-block a second relu of the block and sixteen moves around the branch: 32 wasted
+    // VALU instructions per k-block, 256 per layer, and the block's real relu pulled out of its MFMA gaps into the same
+    // lump.  Same terms in the same order (k-block, then register): sigma keeps its bits.
+    __device__ __forceinline__ void alpha_head(const f32x16* Y) {
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
             const f32x16 w = *reinterpret_cast<const f32x16*>(aw + kb * 32);
-            const f32x16 hx = relu16(y);
+            const f32x16 hx = relu16(Y[kb]);
 #pragma unroll
             for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], hx[t], sigma);
         }
@@ -155,7 +160,7 @@ struct OpInBase {
     }
 };
 __device__ __forceinline__ OpInBase op_in(int lim, const float* aw, float* save = nullptr) {
-    return OpInBase{lim, false, aw, 0.f, save, nullptr, 0u, 0u, {0u, 0u, 0u, 0u}, 0.f, 1.f};
+    return OpInBase{lim, aw, 0.f, save, nullptr, 0u, 0u, {0u, 0u, 0u, 0u}, 0.f, 1.f};
 }
 
 }  // namespace
