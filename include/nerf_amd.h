@@ -240,7 +240,8 @@ int nrf_mlp_backward(const float* packed, const float* packed_t, const float* gr
                      float* grad_flat, nrf_stream_t stream);
 
 /* grad[i] = 2 (x[i] - target[i]) / n: gradient of nn.MSELoss(mean) (src/train/trainers/nerf.py:25-27);
- * if loss_accum is non-NULL, adds mean((x - target)^2) to *loss_accum (zero it first). */
+ * if loss_accum is non-NULL, adds mean((x - target)^2) to *loss_accum (zero it first).  Up to 65536 elements (training
+ * batches) the sum is formed in a fixed order: the same bits on every run; beyond, one float atomic per wavefront. */
 int nrf_mse_grad(const float* x, const float* target, int64_t n, float* grad, float* loss_accum, nrf_stream_t stream);
 
 /* clip_grad_value_(clip_value) then one torch.optim.Adam step (trainer.py:74-75, optimizer.py:9-29) over a

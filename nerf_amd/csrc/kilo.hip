@@ -281,7 +281,8 @@ __device__ __forceinline__ float dot16(const f32x16& w, const f32x16& x) {
 // jobs are 1 .. job_tiles tiles long and a static deal left the waves resident for 84 % of the launch.  A wave holds the
 // number of its next job already (the ticket was drawn a job earlier) and looks that job's cell up -- a scalar binary
 // search, a dozen dependent loads -- while the current job's record is on its way; the results do not depend on who
-// evaluates a point, so raw stays bit-identical.
+// evaluates a point, so raw stays bit-identical.  (job_counter == NULL: the jobs are dealt round-robin, wave w takes jobs
+// w, w + n_waves, ... -- the host's choice for batches with few jobs per wave.)
 __device__ __forceinline__ int job_ticket(int* counter, int lane) {   // the number is in lane 0
     int t = 0;
     if (lane == 0) t = atomicAdd(counter, 1);
@@ -322,8 +323,10 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
     const int j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
     const int total_jobs = job_prefix[ncell];
-    int job = __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane));
-    int ticket = job_ticket(job_counter, lane);   // the job after this one
+    const bool drawn = job_counter != nullptr;    // (uniform) small batches deal the jobs round-robin instead: kilo_forward_impl
+    const int n_waves = gridDim.x * 4;
+    int job = drawn ? __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane)) : int(blockIdx.x) * 4 + wave;
+    int ticket = drawn ? job_ticket(job_counter, lane) : 0;   // the job after this one
     int cell = job < total_jobs ? job_cell_of(job_prefix, ncell, job) : 0;
     for (int job_n = 0, cell_n = 0; job < total_jobs; job = job_n, cell = cell_n) {
         const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloSteps * 256);
             const float4 s0 = src[lane], s1 = src[lane < kKiloSmall / 4 - 64 ? 64 + lane : lane];
             // every load of this job's record is issued: the next job (its ticket was drawn a job ago) gets its cell now
-            job_n = __builtin_amdgcn_readfirstlane(ticket);
-            ticket = job_ticket(job_counter, lane);
+            job_n = drawn ? __builtin_amdgcn_readfirstlane(ticket) : job + n_waves;
+            if (drawn) ticket = job_ticket(job_counter, lane);
             cell_n = job_n < total_jobs ? job_cell_of(job_prefix, ncell, job_n) : 0;
             reinterpret_cast<float4*>(sm_job)[lane] = s0;
             if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = s1;
@@ -525,8 +528,10 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
     const int j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
     const int total_jobs = job_prefix[ncell];
-    int job = __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane));
-    int ticket = job_ticket(job_counter, lane);   // the job after this one
+    const bool drawn = job_counter != nullptr;    // (uniform) small batches deal the jobs round-robin instead: kilo_forward_impl
+    const int n_waves = gridDim.x * 4;
+    int job = drawn ? __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane)) : int(blockIdx.x) * 4 + wave;
+    int ticket = drawn ? job_ticket(job_counter, lane) : 0;   // the job after this one
     int cell = job < total_jobs ? job_cell_of(job_prefix, ncell, job) : 0;
     for (int job_n = 0, cell_n = 0; job < total_jobs; job = job_n, cell = cell_n) {
         const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
@@ -543,8 +548,8 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloSteps * 256);
             const float4 s0 = src[lane], s1 = src[lane < kKiloSmall / 4 - 64 ? 64 + lane : lane];
             // every load of this job's record is issued: the next job (its ticket was drawn a job ago) gets its cell now
-            job_n = __builtin_amdgcn_readfirstlane(ticket);
-            ticket = job_ticket(job_counter, lane);
+            job_n = drawn ? __builtin_amdgcn_readfirstlane(ticket) : job + n_waves;
+            if (drawn) ticket = job_ticket(job_counter, lane);
             cell_n = job_n < total_jobs ? job_cell_of(job_prefix, ncell, job_n) : 0;
             reinterpret_cast<float4*>(sm_job)[lane] = s0;
             if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = s1;
@@ -741,8 +746,10 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
     const int j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
     const int total_jobs = job_prefix[ncell];
-    int job = __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane));
-    int ticket = job_ticket(job_counter, lane);   // the job after this one
+    const bool drawn = job_counter != nullptr;    // (uniform) small batches deal the jobs round-robin instead: kilo_forward_impl
+    const int n_waves = gridDim.x * 4;
+    int job = drawn ? __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane)) : int(blockIdx.x) * 4 + wave;
+    int ticket = drawn ? job_ticket(job_counter, lane) : 0;   // the job after this one
     int cell = job < total_jobs ? job_cell_of(job_prefix, ncell, job) : 0;
     for (int job_n = 0, cell_n = 0; job < total_jobs; job = job_n, cell = cell_n) {
         const int seg_b = seg_start[cell], seg_e = seg_start[cell + 1];
@@ -761,8 +768,8 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloX3MatFloats);
             const float4 s0 = src[lane], s1 = src[lane < kKiloSmall / 4 - 64 ? 64 + lane : lane];
             // every load of this job's record is issued: the next job (its ticket was drawn a job ago) gets its cell now
-            job_n = __builtin_amdgcn_readfirstlane(ticket);
-            ticket = job_ticket(job_counter, lane);
+            job_n = drawn ? __builtin_amdgcn_readfirstlane(ticket) : job + n_waves;
+            if (drawn) ticket = job_ticket(job_counter, lane);
             cell_n = job_n < total_jobs ? job_cell_of(job_prefix, ncell, job_n) : 0;
             reinterpret_cast<float4*>(sm_job)[lane] = s0;
             if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = s1;
@@ -1196,6 +1203,10 @@ static int kilo_forward_impl(int kind, const KiloSrc* src, const int32_t* done, 
     // tiles of one cell per weight load: up to kJobTiles, fewer for small batches so that every wavefront gets jobs
     int64_t jt = (n_points + 32 * 4 * int64_t(cus) * 4 - 1) / (32 * 4 * int64_t(cus) * 4);
     const int job_tiles = int(jt < 4 ? 4 : jt > kJobTiles ? kJobTiles : jt);
+    // A frame has ~25 jobs per wave and the counter evens out their lengths.  A training batch has about one: there every
+    // wave's first ticket -- thousands of return-value atomics on one word at the kernel's start -- would be the kernel's
+    // time (KiloNeRF training step 0.47 -> 0.55 ms), so few jobs are dealt round-robin, without the counter.
+    if (n_points / (32 * int64_t(job_tiles)) + num_cells < 8 * int64_t(2 * cus) * 4) job_counter = nullptr;
     if (src) {   // hist[cell] = samples routed to the cell: pack those cells, nobody reads the others' records
         kilo_pack_kernel<<<dim3(unsigned(num_cells)), 256, 0, stream>>>(*src, num_cells, hist, done, const_cast<float*>(packed));
         if (packed_t) kilo_pack_t_launch(src->t, num_cells, hist, done, packed_t, stream);

@@ -23,6 +23,41 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, sq / float(n));
 }
 
+// The same for batches of training size (n <= kMseOneBlock elements) in ONE workgroup: every thread owns a fixed set of
+// elements, the partial sums meet in a fixed tree and one thread adds the total to the loss word -- no float atomics, so the
+// loss of a batch has the same bits on every run and every stream (with one atomic per wavefront their order, and the last
+// bit of the sum, depended on which wavefront came first).
+constexpr int64_t kMseOneBlock = 1 << 16;
+__global__ __launch_bounds__(1024) void mse_grad_one_block_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                                  int64_t n, float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float s_part[16];
+    float sq = 0.f;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4 * 1024) {   // four elements per thread and round, their loads in flight together
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * 1024;
+            d[u] = i < n ? x[i] - gt[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * 1024;
+            if (i < n) grad[i] = 2.f * d[u] / float(n);
+            sq = fmaf(d[u], d[u], sq);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_part[w];
+        *loss += t / float(n);
+    }
+}
+
 // torch.optim.Adam (single-tensor path): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
 // denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m / denom.
 struct AdamArgs {
@@ -150,7 +185,10 @@ NRF_EXPORT int nrf_mse_grad(const float* x, const float* target, int64_t n, floa
     const int64_t blocks = (n + 255) / 256;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
     nrf_launch_begin();
-    mse_grad_kernel<<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(x, target, n, grad, loss_accum);
+    if (n <= kMseOneBlock)
+        mse_grad_one_block_kernel<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(x, target, n, grad, loss_accum);
+    else
+        mse_grad_kernel<<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(x, target, n, grad, loss_accum);
     return nrf_launch_status();
 }
 
