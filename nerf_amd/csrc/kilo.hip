@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_kernel(const float* __restric
             // rgb_linear (:159-161)
             float r = dot16(lds16(sm + kKOffRgbW + h * 16), hv), g = dot16(lds16(sm + kKOffRgbW + 32 + h * 16), hv),
                   b = dot16(lds16(sm + kKOffRgbW + 64 + h * 16), hv);
-            r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
+            r = nrf_add_halves(r), g = nrf_add_halves(g), b = nrf_add_halves(b), sigma = nrf_add_halves(sigma);
             if (h == 0 && valid) raw[id] = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
         }
     }
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
             // rgb_linear (:159-161)
             float r = dot16(lds16(sm + kKOffRgbW + h * 16), hv), g = dot16(lds16(sm + kKOffRgbW + 32 + h * 16), hv),
                   b = dot16(lds16(sm + kKOffRgbW + 64 + h * 16), hv);
-            r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
+            r = nrf_add_halves(r), g = nrf_add_halves(g), b = nrf_add_halves(b), sigma = nrf_add_halves(sigma);
             ovf = fmaxf(fmaxf(ovf, dguard), __shfl_xor(ovf, 32));
             if (h == 0 && valid) {
                 float4 o = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
@@ -698,6 +698,21 @@ __global__ __launch_bounds__(256) void kilo_pack_x3_kernel(KiloSrc s, int num_ce
     }
 }
 
+#ifdef KF_STAMP   // diagnostic builds (tools/debug/kilo_fwd_phases.py): s_memtime ticks per phase of kilo_mlp_x3_kernel, summed over all waves
+__device__ unsigned long long g_kf_stamps[16];
+// (the stamp reads the clock in an asm statement that takes the phase's result as an in-out operand: pure arithmetic has no
+// order against a clock read otherwise, and the compiler runs all the reads back to back)
+#define KF_T(i, pin)                                                                  \
+    do {                                                                              \
+        unsigned long long now_;                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_), "+v"(pin) : : "memory"); \
+        kf_acc[i] += now_ - kf_last;   /* (per wave, in scalar registers: one atomic per phase and wave at the kernel's end) */ \
+        kf_last = now_;                                                               \
+    } while (0)
+#else
+#define KF_T(i, pin) do {} while (0)
+#endif
+
 // One 32x32 output block of a tiny layer on the bf16 pipe, six MFMAs per k16-step into one accumulator, small terms first
 // (mlp_bf16x3.hip's order); `wlo`: this lane's lo fragments in LDS, 64 u32x4 per step.
 template <int NKB>
@@ -746,6 +761,11 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
     const int j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
     const int total_jobs = job_prefix[ncell];
+#ifdef KF_STAMP
+    unsigned long long kf_last = __builtin_amdgcn_s_memtime();
+    int kf_none = 0;   // (a stamp with nothing to pin: the phase ends in memory operations)
+    unsigned long long kf_acc[12] = {};
+#endif
     const bool drawn = job_counter != nullptr;    // (uniform) small batches deal the jobs round-robin instead: kilo_forward_impl
     const int n_waves = gridDim.x * 4;
     int job = drawn ? __builtin_amdgcn_readfirstlane(job_ticket(job_counter, lane)) : int(blockIdx.x) * 4 + wave;
@@ -799,6 +819,7 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
             for (int a = 0; a < 3; ++a) pn[a] = pts[id_n * 3u + a];
             di_n = dir_of(id_n);
         }
+        KF_T(0, kf_none);   // job set-up: ticket, record loads issued, small block staged, next job's cell, first gathers issued
         for (int t0 = first; t0 < seg_e && t0 < first + 32 * job_tiles; t0 += 32) {
             const bool valid = t0 + j < seg_e;
             const unsigned id = id_c;
@@ -831,32 +852,46 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
                 id_c = id_n, id_n = id_nn, id_nn = id_nnn, di_c = di_n, di_n = di_nn;
             }
             encode_pe_doubling<10>(px, py, pz, h, e);
+            KF_T(2, e[1]);   // (waits for this tile's point) position encoding
             split_block_x3(sel, e[0], xpe[0]);
             split_block_x3(sel, e[1], xpe[1]);
+            KF_T(3, xpe[1][1][2]);   // its split
             int again = 0;   // keeps the LDS reads below inside the tile loop (kilo_mlp_kernel)
             asm volatile("" : "+v"(again));
             const float* bias_h = bias_job + again;
             const float* sm = sm_job + again;
             const u32x4* wlo = wlo_job + again;
             f32x16 y = relu16(tiny_layer_x3<2>(w, wlo, lds16(bias_h), xpe));                        // pts_linears 0 (network.py:132-138)
+            KF_T(4, y);
             split_block_x3(sel, y, xh[0]);
+            KF_T(5, xh[0][1][2]);
             y = relu16(tiny_layer_x3<1>(w + 4, wlo + 4 * 64, lds16(bias_h + 32), xh));            // pts_linears 1
+            KF_T(6, y);
             float sigma = dot16(lds16(sm + kKOffSigW + h * 16), y);                                 // sigma_linear (:142-144)
             split_block_x3(sel, y, xh[0]);
+            KF_T(7, xh[0][1][2]);
             y = tiny_layer_x3<1>(w + 6, wlo + 6 * 64, lds16(bias_h + 64), xh);                     // feature_linear (:147-149), no activation
+            KF_T(8, y);
             split_block_x3(sel, y, xv[0]);
+            KF_T(9, xv[0][1][2]);
             if (!TABLE) {
                 encode_pe_doubling<4>(dx, dy, dz, h, e);
                 split_block_x3(sel, e[0], xv[1]);
             }
-            const f32x16 hv = relu16(tiny_layer_x3<2>(w + 8, wlo + 8 * 64, lds16(bias_h + 96), xv));   // view_linears on cat([feature, dirs]) (:152-156)
+            f32x16 hv = relu16(tiny_layer_x3<2>(w + 8, wlo + 8 * 64, lds16(bias_h + 96), xv));   // view_linears on cat([feature, dirs]) (:152-156)
+            KF_T(10, hv);  // (waits for the tile's direction rows)
             // rgb_linear (:159-161)
             float r = dot16(lds16(sm + kKOffRgbW + h * 16), hv), g = dot16(lds16(sm + kKOffRgbW + 32 + h * 16), hv),
                   b = dot16(lds16(sm + kKOffRgbW + 64 + h * 16), hv);
-            r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32), sigma += __shfl_xor(sigma, 32);
+            r = nrf_add_halves(r), g = nrf_add_halves(g), b = nrf_add_halves(b), sigma = nrf_add_halves(sigma);
             if (h == 0 && valid) raw[id] = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
+            KF_T(11, kf_none);  // heads and store
         }
     }
+#ifdef KF_STAMP
+    if (lane == 0)
+        for (int q = 0; q < 12; ++q) atomicAdd(&g_kf_stamps[q], kf_acc[q]);
+#endif
 }
 
 // ---- generic exclusive scan of int32 (three small kernels) ---------------------------------
@@ -1309,6 +1344,17 @@ NRF_EXPORT int nrf_kilo_forward_bf16x3(const float* packed_x3, int num_cells, co
     return kilo_forward_impl(2, nullptr, nullptr, nullptr, packed_x3, num_cells, aabb_host, res_host, pts, dirs, dir_index, n_points,
                              raw, workspace, workspace_bytes, stream);
 }
+
+#ifdef KF_STAMP
+NRF_EXPORT int nrf_debug_kf_stamps(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_kf_stamps), sizeof(g_kf_stamps)) != hipSuccess) return NRF_ERR_RUNTIME;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_kf_stamps), z, sizeof(z)) != hipSuccess) return NRF_ERR_RUNTIME;
+    }
+    return NRF_OK;
+}
+#endif
 
 NRF_EXPORT int nrf_kilo_pack_weights_fp16x2(const float* const* tensors, int num_cells, float* packed_h2, nrf_stream_t stream) {
     if (!tensors || !packed_h2) return NRF_ERR_NULL;

@@ -52,6 +52,12 @@ __device__ __forceinline__ float nrf_wave_scan_add(float p) {  // inclusive sum;
     return p;
 }
 __device__ __forceinline__ float nrf_lane_shr1(float identity, float v) { return nrf_dpp<0x138>(identity, v); }  // wave_shr:1
+// v + (v of the lane 32 away): the two lane halves of a wavefront added, in every lane, by ONE v_permlane32_swap and an add
+// (__shfl_xor(v, 32) is a ds_bpermute: a trip through the LDS crossbar and a wait).  {lo, hi} + {hi, lo}: the same sum in both halves.
+__device__ __forceinline__ float nrf_add_halves(float v) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
 __device__ __forceinline__ float nrf_read_lane63(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
