@@ -943,6 +943,10 @@ __global__ void scan_add_kernel(int* __restrict__ out, int64_t n, const int* __r
 }
 
 // ---- occupancy-grid ray marching (own specification) ----------------
+#ifndef KILO_RAY_STRIDE_BLOCKS
+#define KILO_RAY_STRIDE_BLOCKS 32768
+#endif
+constexpr int64_t kRayStrideBlocks = KILO_RAY_STRIDE_BLOCKS;   // grid of the ray-striding kernels (4 waves each)
 struct March {
     Grid g;          // scene box + occupancy resolution
     float t_near, t_far, step;
@@ -1067,14 +1071,13 @@ __global__ __launch_bounds__(256) void kilo_march_write_masks_kernel(March m, co
                                                                      int* __restrict__ ray_idx, float* __restrict__ t_start,
                                                                      float* __restrict__ t_end) {
     const int lane = threadIdx.x & 63;
-    const int64_t ray = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (ray >= n_rays) return;
+    for (int64_t ray = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); ray < n_rays; ray += int64_t(gridDim.x) * 4) {   // (kilo_composite_kernel)
     const int n = counts[ray];
-    if (n == 0) return;
+    if (n == 0) continue;
     const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2]};
     const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
     float t0, t1;
-    if (!ray_box(m, o, d, t0, t1)) return;
+    if (!ray_box(m, o, d, t0, t1)) continue;
     const int nsteps = int(ceilf((t1 - t0) / m.step));
     const int nchunks = min((nsteps + 63) >> 6, max_chunks);
     int pos0 = offsets[ray];
@@ -1099,6 +1102,7 @@ __global__ __launch_bounds__(256) void kilo_march_write_masks_kernel(March m, co
             pos0 += __popcll(mask);
         }
     }
+    }
 }
 
 // ---- packed compositing with early ray termination (own specification) -----------------------
@@ -1109,9 +1113,19 @@ __global__ __launch_bounds__(256) void kilo_composite_kernel(const float4* __res
                                                              float* __restrict__ rgb_map, float* __restrict__ depth_map,
                                                              float* __restrict__ acc_map) {
     const int lane = threadIdx.x & 63;
-    const int64_t ray = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (ray >= n_rays) return;
+    // Waves stride over the rays: most rays of a frame march through no occupied voxel (78 % on the bench's scene), and a
+    // wave launched per such ray costs more than the ray -- an empty ray is one load and one store here.
+    for (int64_t ray = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); ray < n_rays; ray += int64_t(gridDim.x) * 4) {
     const int base = offsets[ray], n = counts[ray];
+    if (n == 0) {   // what the sums below come to without samples: background, no depth, no opacity
+        if (lane == 63) {
+            const float bg = white_bkgd ? 1.f : 0.f;
+            rgb_map[ray * 3] = bg, rgb_map[ray * 3 + 1] = bg, rgb_map[ray * 3 + 2] = bg;
+            depth_map[ray] = 0.f;
+            acc_map[ray] = 0.f;
+        }
+        continue;
+    }
     float carry = 1.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f, sd = 0.f;
     // the next chunk's loads are issued before this chunk's scan (the termination test serialises the chunks of a
     // ray otherwise: load -> scan -> test -> load ...); a chunk fetched behind the termination point is not used
@@ -1142,6 +1156,7 @@ __global__ __launch_bounds__(256) void kilo_composite_kernel(const float4* __res
         rgb_map[ray * 3] = sr + bg, rgb_map[ray * 3 + 1] = sg + bg, rgb_map[ray * 3 + 2] = sb + bg;
         depth_map[ray] = sd / fmaxf(sa, 1.1920929e-07f);
         acc_map[ray] = sa;
+    }
     }
 }
 
@@ -1513,7 +1528,7 @@ NRF_EXPORT int nrf_kilo_march_write(const float* rays_o, const float* rays_d, in
         if (workspace_bytes < nrf_kilo_march_workspace_bytes(n_rays, t_near, t_far, step)) return NRF_ERR_WORKSPACE;
         auto* masks = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(workspace) + march_scan_bytes(n_rays));
         nrf_launch_begin();
-        kilo_march_write_masks_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(m, rays_o, rays_d, n_rays, counts, offsets,
+        kilo_march_write_masks_kernel<<<dim3((unsigned)(blocks < kRayStrideBlocks ? blocks : kRayStrideBlocks)), 256, 0, stream>>>(m, rays_o, rays_d, n_rays, counts, offsets,
                                                                                    masks, mc, pts, ray_idx, t_start, t_end);
         return nrf_launch_status();
     }
@@ -1536,7 +1551,7 @@ NRF_EXPORT int nrf_kilo_composite(const float* raw, const float* t_start, const 
     const int64_t blocks = (n_rays + 3) / 4;
     if (blocks > 0x7fffffffLL) return NRF_ERR_SHAPE;
     nrf_launch_begin();
-    kilo_composite_kernel<<<dim3((unsigned)blocks), 256, 0, static_cast<hipStream_t>(stream)>>>(
+    kilo_composite_kernel<<<dim3((unsigned)(blocks < kRayStrideBlocks ? blocks : kRayStrideBlocks)), 256, 0, static_cast<hipStream_t>(stream)>>>(
         reinterpret_cast<const float4*>(raw), t_start, t_end, offsets, counts, n_rays, ert_eps, white_bkgd, rgb_map,
         depth_map, acc_map);
     return nrf_launch_status();
