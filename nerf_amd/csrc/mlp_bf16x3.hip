@@ -119,6 +119,70 @@ __device__ __forceinline__ void xr_start(XRing& st, const char* stream_base, cha
 }
 
 
+// The same ring with the stream addressed as a UNIFORM base (an SGPR pair that walks the chunks) + one 32-bit lane offset
+// (global_load_lds_dwordx4 voff, s[base]) instead of three per-lane 64-bit pointers: five registers fewer, and no
+// vector arithmetic on addresses (the 16x16x32 kernel below: one of those pointers lived in scratch, and every reload's
+// wait drained the ring).
+struct XRingS {
+    const char* snext;   // uniform: this wave's piece 0 of the next chunk to prefetch
+    const char* sbegin;
+    const char* send;
+    unsigned voff;       // lane * 16
+    unsigned lds_base;
+    char* smem;
+    int pf_slot, rd_slot;
+    const u32x4* rd;
+    u32x4 wq[4][3];
+};
+__device__ __forceinline__ void xr_piece(const XRingS& st, int j) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(st.voff), "s"(st.snext + j * 1024),
+          "s"(__builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kXChunkBytes + j * 1024))
+        : "memory");
+}
+__device__ __forceinline__ void xr_advance(XRingS& st) {
+    const char* nx = st.snext + kXChunkBytes;
+    st.snext = nx == st.send ? st.sbegin : nx;
+    asm volatile("" : "+s"(st.snext));  // keep it a run-time value (see ws_prefetch_advance)
+    st.pf_slot = st.pf_slot + 1 == kXRing ? 0 : st.pf_slot + 1;
+}
+__device__ __forceinline__ void xr_acquire(XRingS& st, int lane) {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(kXPieces * (kXRing - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = st.rd_slot + 1 == kXRing ? 0 : st.rd_slot + 1;
+    st.rd = reinterpret_cast<const u32x4*>(st.smem + st.rd_slot * kXChunkBytes) + lane;
+}
+__device__ __forceinline__ void xr_read1(XRingS& st, int slot, int step_in_chunk, int t) {
+    st.wq[slot][t] = st.rd[(step_in_chunk * 3 + t) * 64];
+}
+__device__ __forceinline__ void xr_start(XRingS& st, const char* stream_base, char* smem, int wave, int lane) {
+    st.sbegin = stream_base + wave * (kXPieces * 1024);
+    st.send = st.sbegin + size_t(kXChunks) * kXChunkBytes;
+    st.snext = st.sbegin;
+    st.voff = unsigned(lane) * 16u;
+    st.smem = smem;
+    st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * unsigned(kXPieces * 1024));
+    st.pf_slot = 0;
+#pragma unroll
+    for (int i = 0; i < kXRing; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < (i + 1 < kXRing ? kXPieces : kXLook); ++jj) xr_piece(st, jj);
+        if (i + 1 < kXRing) xr_advance(st);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kXPieces * (kXRing - 2) + kXLook) : "memory");
+    __builtin_amdgcn_s_barrier();
+    st.rd_slot = 0;
+    st.rd = reinterpret_cast<const u32x4*>(smem) + lane;
+#pragma unroll
+    for (int i = 0; i < kXLook; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) xr_read1(st, i, i, t);
+}
+
 // Input op of a hidden-type layer: X[kb] (three-term B fragments) from Y[kb] of the previous layer, in eight slices of
 // one register pair each (15 VALU instructions per slice behind OpInBase's activation).
 struct OpIn : OpInBase {
@@ -127,8 +191,8 @@ struct OpIn : OpInBase {
     float sa, sb, ra, rb;
     unsigned p0, p1;
     SplitSel k;   // the residuals by v_dot2c_f32_bf16 (split3.h): 3 + 3 + 3 instructions per pair behind the activation
-    template <int MODE>
-    __device__ __forceinline__ void input(const f32x16& y, int blk, int q, float& a, float& b) {
+    template <int MODE, class YT>
+    __device__ __forceinline__ void input(const YT& y, int blk, int q, float& a, float& b) {
         if (MODE == kOpBwd) {
             const float2 w = *reinterpret_cast<const float2*>(aw + blk * 32 + 2 * q);
             const int word = int(m[blk >> 1]), at = 16 * (blk & 1) + 2 * q;   // (split_stream.h: OpInBase::input)
@@ -140,8 +204,8 @@ struct OpIn : OpInBase {
         }
         keep<MODE>(blk, q, a, b);
     }
-    template <int MODE>
-    __device__ __forceinline__ void sub(const f32x16& y, u32x4 (&x)[2][3], int blk, int q, int phase) {
+    template <int MODE, class YT>
+    __device__ __forceinline__ void sub(const YT& y, u32x4 (&x)[2][3], int blk, int q, int phase) {
         if (phase == 0) {
             input<MODE>(y, blk, q, sa, sb);
             p0 = pk_bf16(sa, sb);
@@ -162,8 +226,8 @@ struct OpIn : OpInBase {
             x[q / 4][2][q % 4] = pk_bf16(minus_bf(ra, p1, k.lo), minus_bf(rb, p1, k.hi));
         }
     }
-    template <int MODE>
-    __device__ __forceinline__ void pair(const f32x16& y, u32x4 (&x)[2][3], int blk, int q) {
+    template <int MODE, class YT>
+    __device__ __forceinline__ void pair(const YT& y, u32x4 (&x)[2][3], int blk, int q) {
         float a, b;
         input<MODE>(y, blk, q, a, b);
         unsigned p0, p1, p2;
@@ -396,6 +460,301 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 }
 
+// ---- the inference forward on v_mfma_f32_16x16x32_bf16 --------------------------------------------------------------------
+// Same chain, same stream positions, same VALU work; the matrix shape is the change.  Under this kernel's load the chip
+// holds its clock by the energy a FLOP costs, and the 16x16x32 shape costs less than the 32x32x16 one at the same cycles
+// per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7; tools/ubench/mfma_shape_clock.hip models this kernel's step:
+// 1.66 -> 1.91 GHz; a timing-only build of the kernel above with every MFMA replaced by two of the other shape: -7 %).
+// A step at stream position (ob, kb, s2) is the three weight terms of rows 32 ob + 16 s2 .. + 15 against ALL 32 features of
+// k-block kb (the 32x32 form: 32 rows against the 16 features of half s2), multiplied into two 16-point accumulators.
+// Layout (split_stream.h: m16_slot): lane (c = lane & 15, g = lane >> 4); a block's 16 registers are four 16 x 16
+// accumulators q[2 nb + mh]; register 8 nb + 4 mh + r is feature 16 mh + 4 g + r of point 16 nb + c -- so the eight
+// registers of one nb are, in order, the lane's eight k-values of the next layer's B fragment, and the input op, the
+// operand split and the fragment arrays X[kb][nb][term] of the 32x32 form are used unchanged (its s2 index is nb here).
+#define NRF_MFMA_X16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+struct Blk16 {   // kept as ONE 16-register value (four separate quarters: the allocator parked finished quarters in AGPRs / scratch)
+    f32x16 v;
+    __device__ __forceinline__ float operator[](int t) const { return v[t]; }
+};
+template <int MH>
+__device__ __forceinline__ void blk16_get(const Blk16& y, f32x4& a, f32x4& b) {
+    a = __builtin_shufflevector(y.v, y.v, 4 * MH, 4 * MH + 1, 4 * MH + 2, 4 * MH + 3);
+    b = __builtin_shufflevector(y.v, y.v, 8 + 4 * MH, 8 + 4 * MH + 1, 8 + 4 * MH + 2, 8 + 4 * MH + 3);
+}
+template <int MH>
+__device__ __forceinline__ void blk16_put(Blk16& y, const f32x4& a, const f32x4& b) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y.v[4 * MH + t] = a[t], y.v[8 + 4 * MH + t] = b[t];
+}
+
+// the small fp32 block of the 16x16x32 stream, in floats from its start
+constexpr int kS16AlphaW = 9 * 512 + 256;         // biases [layer 0..9][block][g][16] before it (views_linears: 4 blocks)
+constexpr int kS16AlphaB = kS16AlphaW + 256;      // alpha weights [block][g][8]
+constexpr int kS16RgbW = kS16AlphaB + 16;         // rgb weights [c][block 0..3][g][8]
+constexpr int kS16RgbB = kS16RgbW + 3 * 128;
+constexpr int kS16Floats = kS16RgbB + 16;         // 5536
+constexpr int64_t kX16StreamOff = (kXSmallFloatOff + kSmallFloats) * 4;                  // bytes from the start of the pack
+constexpr int64_t kX16SmallOff = kX16StreamOff + int64_t(kXStreamSteps) * kXStepBytes;
+constexpr int64_t kXPackedBytes = kX16SmallOff + int64_t(kS16Floats) * 4;
+static_assert(kX16StreamOff % 16 == 0 && kX16SmallOff % 16 == 0, "LDS-DMA and float4 alignment");
+constexpr int kX16LdsBytes = kXLdsConstOff + kS16Floats * 4;                             // 120 KiB + 21.6 KiB
+static_assert(kX16LdsBytes <= 160 * 1024, "LDS budget");
+
+struct PackSmall16 {
+    const float* bias[10];  // pts0..7, feature, views
+    const float* alpha_w;
+    const float* alpha_b;
+    const float* rgb_w;
+    const float* rgb_b;
+    float* dst;
+};
+__global__ void pack_small16_kernel(PackSmall16 p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kS16Floats) return;
+    float v = 0.f;
+    if (idx < kS16AlphaW) {
+        const int layer = idx >> 9, t = idx & 15, g = (idx >> 4) & 3, sb = (idx >> 6) & 7;
+        v = p.bias[layer][32 * sb + m16_slot(g, t & 7)];
+    } else if (idx < kS16AlphaB) {
+        const int i = idx - kS16AlphaW;
+        v = p.alpha_w[32 * (i >> 5) + m16_slot((i >> 3) & 3, i & 7)];
+    } else if (idx < kS16RgbW) {
+        v = idx == kS16AlphaB ? p.alpha_b[0] : 0.f;
+    } else if (idx < kS16RgbB) {
+        const int i = idx - kS16RgbW;
+        v = p.rgb_w[(i >> 7) * 128 + 32 * ((i >> 5) & 3) + m16_slot((i >> 3) & 3, i & 7)];
+    } else {
+        v = idx - kS16RgbB < 3 ? p.rgb_b[idx - kS16RgbB] : 0.f;
+    }
+    p.dst[idx] = v;
+}
+
+// An encoding block made in the 32x32 form (register t of lane (j, h): slot acc_row(t, h) of point j) handed over to the
+// 16x16x32 form: register 8 nb + 4 mh + r of lane (c, g) is register 4 (2 mh + (g >> 1)) + r of lane 32 (g & 1) + 16 nb + c.
+// Per register pair (A = 4 (2 mh) + r, B = A + 4): rows of 16 lanes [A0 A1 A2 A3], [B0 B1 B2 B3] -> v_permlane32_swap ->
+// [A0 A1 B0 B1], [A2 A3 B2 B3] -> v_permlane16_swap -> [A0 A2 B0 B2] (nb = 0), [A1 A3 B1 B3] (nb = 1).  Two VALU
+// instructions per pair, no LDS.
+__device__ __forceinline__ f32x16 to_m16(const f32x16& e) {
+    f32x16 r;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e[8 * mh + rr]), __float_as_uint(e[8 * mh + 4 + rr]), false, false);
+            const auto s16 = __builtin_amdgcn_permlane16_swap(s32[0], s32[1], false, false);
+            r[4 * mh + rr] = __uint_as_float(s16[0]);
+            r[8 + 4 * mh + rr] = __uint_as_float(s16[1]);
+        }
+    return r;
+}
+// Head sums of the 16x16x32 form: a lane holds partial sums of TWO points (v0: point c, v1: point 16 + c) over its group's
+// features.  Returns, in even groups, the sum of v0 over the four groups and in odd groups that of v1 (lane l < 32 then
+// holds point l's): the first exchange hands the neighbour group the half it keeps.
+__device__ __forceinline__ float add_groups(float v0, float v1, bool odd) {
+    const float mine = (odd ? v1 : v0) + __shfl_xor(odd ? v0 : v1, 16);
+    return mine + __shfl_xor(mine, 32);
+}
+
+template <class Hook>
+__device__ __forceinline__ void x16_step(XRingS& st, int lane, int s, Blk16& y, int mh, const u32x4* xk /* [nb][term] */,
+                                         Hook&& hook) {
+    f32x4 ya, yb;
+    if (mh) blk16_get<1>(y, ya, yb);
+    else blk16_get<0>(y, ya, yb);
+    const int piece = (s + kXLook) % kXChunkSteps;   // ring hand-over and refill exactly as x3_step
+    const bool hand = piece == 0;
+    const u32x4 w0 = st.wq[s & 3][0], w1 = st.wq[s & 3][1], w2 = st.wq[s & 3][2];
+    if (hand) xr_acquire(st, lane);
+    const int rs = (s + kXLook) & 3, rc = (s + kXLook) % kXChunkSteps;
+    // a gap = the same product for both point halves (2 x 16 matrix cycles); small terms first, as x3_step
+#define X16_GAP(m, wa, t, RD)                                                                            \
+    ya = NRF_MFMA_X16(wa, xk[t], ya);                                                                    \
+    yb = NRF_MFMA_X16(wa, xk[3 + t], yb);                                                                \
+    RD;                                                                                                  \
+    if (m == 4 && piece < kXPieces) { xr_piece(st, piece); if (piece == kXPieces - 1) xr_advance(st); }  \
+    hook(m);                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
+    X16_GAP(0, w2, 0, xr_read1(st, rs, rc, 0))
+    X16_GAP(1, w0, 2, xr_read1(st, rs, rc, 1))
+    X16_GAP(2, w1, 1, xr_read1(st, rs, rc, 2))
+    X16_GAP(3, w1, 0, (void)0)
+    X16_GAP(4, w0, 1, (void)0)
+    X16_GAP(5, w0, 0, (void)0)
+#undef X16_GAP
+    if (mh) blk16_put<1>(y, ya, yb);
+    else blk16_put<0>(y, ya, yb);
+}
+
+__device__ __forceinline__ Blk16 bias16(const float* bias_g, int ob) {
+    return Blk16{*reinterpret_cast<const f32x16*>(bias_g + ob * 64)};
+}
+
+__device__ __forceinline__ void x16_pe_layer(XRingS& st, int lane, const float* bias_g, bool accum, const u32x4 (*pe)[2][3], Blk16* Y) {
+    auto none = [](int) {};
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) {
+        const Blk16 bias = bias16(bias_g, ob);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Y[ob].v[t] = accum ? Y[ob].v[t] : bias.v[t];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                x16_step(st, lane, (ob * 2 + kb) * 2 + s2, Y[ob], s2, pe[kb][0], none);
+    }
+}
+
+// x3_hidden_layer in the 16x16x32 form (forward only)
+template <int NOB, int NPOST, int NHID = 8>
+__device__ __forceinline__ void x16_hidden_layer(XRingS& st, int lane, const float* bias_g, u32x4 (*X)[2][3],
+                                                 const u32x4 (*post)[2][3], Blk16* Y, Blk16& Z, OpIn& op) {
+    constexpr int NKB = NHID + NPOST;
+    static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
+#pragma unroll
+    for (int q = 0; q < 8; ++q) op.template pair<kOpFwd>(Y[0], X[0], 0, q);
+    Y[0] = bias16(bias_g, 0);
+    Z = bias16(bias_g, 1);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const bool make = kb + 1 < NHID;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4* xk = kb < NHID ? X[kb][0] : post[kb - NHID][0];
+                const int g = b * 2 + s2;
+                auto hook = [&](int m) {
+                    const int n = g * 6 + m;
+                    if (make) op.template sub<kOpFwd>(Y[kb + 1], X[kb + 1], kb + 1, n / 3, n % 3);
+                    if (kb == NKB - 1 && g == 3 && m == 0 && NOB > 2) Y[2] = bias16(bias_g, 2);
+                };
+                Blk16& y = b == 0 ? Y[0] : Z;
+                x16_step(st, lane, kb * 4 + g, y, s2, xk, hook);
+            }
+    }
+    Y[1] = Z;
+#pragma unroll
+    for (int ob = 2; ob < NOB; ++ob) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                auto hook = [&](int m) {
+                    if (kb == NKB - 1 && s2 == 1 && m == 0 && ob + 1 < NOB) Y[ob + 1] = bias16(bias_g, ob + 1);
+                };
+                x16_step(st, lane, (ob * NKB + kb) * 2 + s2, Y[ob], s2, kb < NHID ? X[kb][0] : post[kb - NHID][0], hook);
+            }
+    }
+}
+
+// The kernel above (SAVE = false) in the 16x16x32 form.  `stream` / `small16`: the second half of the pack.
+__global__ __launch_bounds__(256, 1) void mlp_bf16x3_m16_kernel(const char* __restrict__ stream, const float* __restrict__ small16,
+                                                                const float* __restrict__ a0, const float* __restrict__ a1,
+                                                                const float* __restrict__ zbuf, int64_t z_stride, int tiles_per_ray,
+                                                                int rays_mode, int64_t n_points, int64_t n_groups,
+                                                                float4* __restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5, g = lane >> 4;
+    {
+        const float4* src = reinterpret_cast<const float4*>(small16);
+        float4* dst = reinterpret_cast<float4*>(smem + kXLdsConstOff);
+        for (int i = threadIdx.x; i < kS16Floats / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* cst = reinterpret_cast<const float*>(smem + kXLdsConstOff);
+    const float* bias_g = cst + g * 16;
+
+    XRingS st;
+    xr_start(st, stream, smem, wave, lane);
+    const SplitSel sel = SplitSel::make();
+
+    for (int64_t tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+        const int64_t tile = tg * 4 + wave;
+        int64_t pidx = tile * 32 + j;   // the point whose encoding this lane makes (32x32 form) and, in lanes 0..31, stores
+        const bool valid = pidx < n_points;
+        if (!valid) pidx = n_points - 1;
+        float px, py, pz, dx, dy, dz;
+        if (rays_mode) {
+            const int64_t tile_c = pidx / 32;
+            const int64_t ray = tile_c / tiles_per_ray;
+            const int s0 = int(tile_c - ray * tiles_per_ray) * 32;
+            const float ox = a0[ray * 3 + 0], oy = a0[ray * 3 + 1], oz = a0[ray * 3 + 2];
+            dx = a1[ray * 3 + 0], dy = a1[ray * 3 + 1], dz = a1[ray * 3 + 2];
+            const float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));  // volume_renderer.py:230 (torch's 3-element norm)
+            dx = dx / nrm, dy = dy / nrm, dz = dz / nrm;
+            const float zz = zbuf[ray * z_stride + s0 + (valid ? j : int(pidx & 31))];
+            px = __fadd_rn(ox, __fmul_rn(zz, dx));  // :231
+            py = __fadd_rn(oy, __fmul_rn(zz, dy));
+            pz = __fadd_rn(oz, __fmul_rn(zz, dz));
+        } else {
+            px = a0[pidx * 3 + 0], py = a0[pidx * 3 + 1], pz = a0[pidx * 3 + 2];
+            dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
+        }
+        u32x4 pe[2][2][3], dpe[1][2][3];
+        split_block_x3(sel, to_m16(encode_block<10, 0>(px, py, pz, h)), pe[0]);
+        split_block_x3(sel, to_m16(encode_block<10, 1>(px, py, pz, h)), pe[1]);
+        split_block_x3(sel, to_m16(encode_block<4, 0>(dx, dy, dz, h)), dpe[0]);
+
+        u32x4 X[8][2][3];
+        Blk16 Y[8], Z;
+        OpIn op{op_in(kActRelu, nullptr), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
+        float sig0 = 0.f, sig1 = 0.f;
+        for (int li = 1; li <= 8; ++li) {
+            if (li == 1 || li == 6) x16_pe_layer(st, lane, bias_g + (li == 1 ? 0 : 5 * 512), li == 6, pe, Y);
+            if (li == 8) {   // alpha_linear on relu(h7): one lump in front of feature_linear (OpInBase::alpha_head)
+                const float* aw = cst + kS16AlphaW + g * 8;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    const f32x4 wl = *reinterpret_cast<const f32x4*>(aw + kb * 32), wh = *reinterpret_cast<const f32x4*>(aw + kb * 32 + 4);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float w = t < 4 ? wl[t] : wh[t - 4];
+                        const int b0 = __float_as_int(Y[kb][t]), b1 = __float_as_int(Y[kb][8 + t]);
+                        sig0 = fmaf(w, __int_as_float(b0 > 0 ? b0 : 0), sig0);
+                        sig1 = fmaf(w, __int_as_float(b1 > 0 ? b1 : 0), sig1);
+                    }
+                }
+            }
+            x16_hidden_layer<8, 0>(st, lane, bias_g + li * 512, X, nullptr, Y, Z, op);
+        }
+        asm volatile("" : "+v"(sig0), "+v"(sig1));   // keep the head where it is (see mlp_bf16.hip)
+        OpIn op_views{op_in(kActNone, nullptr), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
+        x16_hidden_layer<4, 1>(st, lane, bias_g + 9 * 512, X, dpe, Y, Z, op_views);   // views_linears.0
+        float c0[3] = {0.f, 0.f, 0.f}, c1[3] = {0.f, 0.f, 0.f};
+        {
+            const float* rw = cst + kS16RgbW + g * 8;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 wl = *reinterpret_cast<const f32x4*>(rw + c * 128 + kb * 32);
+                    const f32x4 wh = *reinterpret_cast<const f32x4*>(rw + c * 128 + kb * 32 + 4);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float w = t < 4 ? wl[t] : wh[t - 4];
+                        const int b0 = __float_as_int(Y[kb][t]), b1 = __float_as_int(Y[kb][8 + t]);
+                        c0[c] = fmaf(w, __int_as_float(b0 > 0 ? b0 : 0), c0[c]);
+                        c1[c] = fmaf(w, __int_as_float(b1 > 0 ? b1 : 0), c1[c]);
+                    }
+                }
+        }
+        // lanes 0..15 hold point c of the tile, lanes 16..31 point 16 + c: lane l < 32 stores point l
+        const bool odd = (g & 1) != 0;
+        const float r = add_groups(c0[0], c1[0], odd), gg = add_groups(c0[1], c1[1], odd);
+        const float b = add_groups(c0[2], c1[2], odd), sg = add_groups(sig0, sig1, odd);
+        if (lane < 32 && valid) {
+            const float* rb = cst + kS16RgbB;
+            raw[pidx] = make_float4(r + rb[0], gg + rb[1], b + rb[2], sg + cst[kS16AlphaB]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+}
+
 // ---- backward data-gradient chain on the same machinery (mlp_bwd.hip: mlp_dgrad_kernel is the fp32 MFMA form) -------
 // d(input of layer l) = W_l^T . dY_l with the transposed weights as the three-term stream (views^T, feature^T,
 // pts7^T .. pts1^T; nrf_pack_weights_transposed_bf16x3), dY_l = relu'(h_l) * d h_l from the sign words the training
@@ -505,6 +864,21 @@ int launch_x3(const void* packed, const float* a0, const float* a1, const float*
     }
     const unsigned grid = unsigned(groups < cus ? groups : cus);
     nrf_launch_begin();
+    if (!acts) {   // inference: the 16x16x32 form, on the second stream of the pack
+        static bool attr16_set[64] = {};
+        if (dev >= 0 && dev < 64 && !attr16_set[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16x3_m16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kX16LdsBytes) != hipSuccess)
+                return NRF_ERR_LAUNCH;
+            attr16_set[dev] = true;
+        }
+        const char* base = static_cast<const char*>(packed);
+        mlp_bf16x3_m16_kernel<<<dim3(grid), 256, kX16LdsBytes, stream>>>(base + kX16StreamOff,
+                                                                        reinterpret_cast<const float*>(base + kX16SmallOff), a0, a1, z,
+                                                                        z_stride, tiles_per_ray, rays_mode, n_points, groups,
+                                                                        reinterpret_cast<float4*>(raw));
+        return nrf_launch_status();
+    }
     if (acts)
         mlp_bf16x3_kernel<true><<<dim3(grid), 256, kXLdsBytes, stream>>>(static_cast<const char*>(packed), a0, a1, z, z_stride,
                                                                          tiles_per_ray, rays_mode, n_points, groups,
@@ -566,7 +940,8 @@ NRF_EXPORT int nrf_pack_weights_transposed_bf16x3(const float* const* w, void* p
 }
 
 
-NRF_EXPORT int64_t nrf_packed_bf16x3_bytes(void) { return kXSmallFloatOff * 4 + int64_t(kSmallFloats) * 4; }
+// the pack: [32x32x16 stream | its small block] for the training forward, [16x16x32 stream | its small block] for inference
+NRF_EXPORT int64_t nrf_packed_bf16x3_bytes(void) { return kXPackedBytes; }
 
 NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const* b, void* packed, nrf_stream_t stream_) {
     if (!w || !b || !packed) return NRF_ERR_NULL;
@@ -588,6 +963,17 @@ NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const
     xpack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch);
     const PackSmall s = xpack_small(w, b, packed, kXSmallFloatOff);
     pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
+    // the same layers as A fragments of the 16x16x32 form
+    base = reinterpret_cast<unsigned short*>(static_cast<char*>(packed) + kX16StreamOff);
+    n_batch = 0;
+    xpack_forward_layers(w, launch, 2, 1);
+    xpack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch);
+    PackSmall16 s16;
+    for (int l = 0; l < 9; ++l) s16.bias[l] = b[l];
+    s16.bias[9] = b[10];
+    s16.alpha_w = w[9], s16.alpha_b = b[9], s16.rgb_w = w[11], s16.rgb_b = b[11];
+    s16.dst = reinterpret_cast<float*>(static_cast<char*>(packed) + kX16SmallOff);
+    pack_small16_kernel<<<(kS16Floats + 255) / 256, 256, 0, stream>>>(s16);
     return nrf_launch_status();
 }
 

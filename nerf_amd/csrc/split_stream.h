@@ -33,15 +33,29 @@ struct XPackLayer {
     int pre_col0, hid_col0, post_col0;
     int lead;     // hidden-type layers: the stream opens with blocks 0 .. lead-1 interleaved, [kb][ob < lead][s2] (0: plain)
     int transposed;   // backward chain: A = W^T (hidden part only): row = a column of W, k = a row of W
+    int m16;          // A fragments of v_mfma_*_16x16x32 (mlp_bf16x3.hip, M16): the step at the same stream position holds rows
+                      // 32 ob + 16 s2 + (lane & 15) and, in lane group g = lane >> 4, the 8 k of feature slots m16_slot(g, jj)
 };
+// 16x16x32 form: which of a 32-feature block's slots sits at element jj (0..7) of lane group g (0..3) of a B / A fragment.
+// A wave holds a block of a layer's output as four 16 x 16 accumulators (two 16-row halves mh x two 16-point halves nb);
+// register 8 nb + 4 mh + r of lane (c, g) is feature 16 mh + 4 g + r of point 16 nb + c, and the eight registers of one nb
+// are, in order, the lane's eight k-values of the next layer's B fragment.
+__host__ __device__ constexpr int m16_slot(int g, int jj) { return 16 * (jj >> 2) + 4 * g + (jj & 3); }
 __device__ __forceinline__ int xpack_total(const XPackLayer& p) { return p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512; }
 __device__ __forceinline__ float xpack_fetch(const XPackLayer& p, int idx, int& step, int& lane, int& jj) {
     const int nkb = p.pre_kb + p.hid_kb + p.post_kb;
     jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
     int s2 = step & 1, kbpos = (step >> 1) % nkb, ob = (step >> 1) / nkb;
     if (p.lead > 1 && step < 2 * p.lead * nkb) kbpos = step / (2 * p.lead), ob = (step >> 1) % p.lead;
-    const int h = lane >> 5, t = 8 * s2 + jj;
-    const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
+    int h = lane >> 5, t = 8 * s2 + jj;
+    int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
+    if (p.m16) {
+        // slot phi of the block = register t, lane half h of the 32x32 form with acc_row(t, h) == phi: the encoding
+        // blocks are made in that form and handed over register by register (mlp_bf16x3.hip: to_m16)
+        const int phi = m16_slot(lane >> 4, jj);
+        t = 4 * (phi >> 3) + (phi & 3), h = (phi >> 2) & 1;
+        row = int64_t(ob * 32 + 16 * s2 + (lane & 15)) * p.ldw;
+    }
     float v = 0.f;
     if (p.transposed) {
         v = p.W[int64_t(32 * kbpos + acc_row(t, h)) * p.ldw + p.hid_col0 + ob * 32 + (lane & 31)];
@@ -58,16 +72,16 @@ __device__ __forceinline__ float xpack_fetch(const XPackLayer& p, int idx, int& 
 }
 // the forward stream's layers in stream order (kXLayerStep): launch(layer description, first step)
 template <class Launch>
-inline void xpack_forward_layers(const float* const* w, Launch&& launch, int lead = 2) {
-    launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0}, kXLayerStep[0]);
-    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0}, kXLayerStep[l]);
+inline void xpack_forward_layers(const float* const* w, Launch&& launch, int lead = 2, int m16 = 0) {
+    launch(XPackLayer{w[0], nullptr, 63, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0, m16}, kXLayerStep[0]);
+    for (int l = 1; l <= 4; ++l) launch(XPackLayer{w[l], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0, m16}, kXLayerStep[l]);
     // network.py:58 cat([input_pts, h]): hidden columns 63..318 as a plain layer, then the PE columns 0..62 accumulate
-    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0,lead, 0}, kXLayerStep[5]);
-    launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0}, kXLayerStep[6]);
-    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0}, kXLayerStep[7]);
-    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0}, kXLayerStep[8]);
-    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0}, kXLayerStep[9]);      // feature_linear
-    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256,lead, 0}, kXLayerStep[10]);   // views_linears.0
+    launch(XPackLayer{w[5], nullptr, 319, 8, 0, 8, 0, 0, 0, 0, 63, 0,lead, 0, m16}, kXLayerStep[5]);
+    launch(XPackLayer{w[5], nullptr, 319, 8, 2, 0, 0, 10, 0, 0, 0, 0, 0, 0, m16}, kXLayerStep[6]);
+    launch(XPackLayer{w[6], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0, m16}, kXLayerStep[7]);
+    launch(XPackLayer{w[7], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0, m16}, kXLayerStep[8]);
+    launch(XPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0,lead, 0, m16}, kXLayerStep[9]);      // feature_linear
+    launch(XPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256,lead, 0, m16}, kXLayerStep[10]);   // views_linears.0
 }
 // the small fp32 block behind a stream (biases, alpha / rgb head rows: pack_small_kernel's layout)
 inline PackSmall xpack_small(const float* const* w, const float* const* b, void* packed, int64_t small_float_off) {
@@ -143,8 +157,8 @@ struct OpInBase {
             for (int t = 0; t < 16; ++t) sigma = fmaf(w[t], hx[t], sigma);
         }
     }
-    template <int MODE, bool SCALED = false>
-    __device__ __forceinline__ void input(const f32x16& y, int blk, int q, float& a, float& b) {
+    template <int MODE, bool SCALED = false, class YT>   // YT: f32x16, or the 16x16x32 form's block (mlp_bf16x3.hip: Blk16)
+    __device__ __forceinline__ void input(const YT& y, int blk, int q, float& a, float& b) {
         if (MODE == kOpBwd) {
             const float2 w = *reinterpret_cast<const float2*>(aw + blk * 32 + 2 * q);
             // the sign bit as an all-ones / all-zeros word (one v_bfe_i32) and an AND: two instructions per element
