@@ -20,13 +20,17 @@
 // ping-pong between two register arrays.  The LDS ring moves 32-KiB chunks (one barrier per 2048 matrix cycles per
 // SIMD) and its LDS-DMA refills are spread over the chunk's steps.
 //
+// Matrix shape (round 3): v_mfma_f32_16x16x32_bf16 (m16.h) -- a step's 1-KiB weight fragment is 16 rows x 32 k and meets
+// four 16-point accumulators (2 sets x 2 halves); everything else (stream positions, epilogue slices, ring) as it was on
+// 32x32x16.  The chip holds a higher clock on this shape.
+//
 // Tiling (template NSETS = 2): four waves per workgroup, one per SIMD, each owning two 32-point sets that share every
 // weight operand (one ds_read_b128 per 2 MFMAs); a workgroup covers 256 points per pass of the weight stream.
 // NSETS = 1 -- eight waves, two per SIMD, one set each, everything in the 256 architectural VGPRs, no VGPR<->AGPR
 // copies -- was built and measured in round 2: 8 % fewer cycles, but twice the LDS read bytes per MFMA, and the chip
 // answered with a 9 % lower clock (1.72 vs 1.89 GHz, GRBM_GUI_ACTIVE): 10.99 vs 10.95 ms per 65,536-ray fine pass.  The
 // template parameter stays (the code is generic in it); only NSETS = 2 is instantiated.
-#include "mlp_chain.h"
+#include "m16.h"
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -55,7 +59,8 @@ constexpr int kBLayerStep[10] = {0, 32, 160, 288, 416, 544, 704, 832, 960, 1120}
 constexpr int kBAlphaStep = 1088;
 constexpr int64_t kBSmallFloatOff = int64_t(kBStreamSteps) * 256;  // small block (fp32) behind the stream
 constexpr int kBLdsConstOff = kBRing * kBChunkBytes;               // 128 KiB
-constexpr int kBLdsBytes = kBLdsConstOff + kSmallFloats * 4;       // + 12.1 KiB
+constexpr int kBLdsBytes = kBLdsConstOff + kS16Floats * 4;         // + 21.6 KiB (m16.h: the small block of the 16x16x32 form)
+static_assert(kBLdsBytes <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round to nearest even
@@ -89,15 +94,19 @@ __global__ void bpack_layer_kernel(BPackLayer p) {
     if (idx >= total) return;
     const int jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
     const int s2 = step & 1, kbpos = (step >> 1) % nkb, ob = (step >> 1) / nkb;
-    const int h = lane >> 5, t = 8 * s2 + jj;
-    const int64_t row = int64_t(ob * 32 + (lane & 31)) * p.ldw;
+    // A fragment of the 16x16x32 form (split_stream.h: xpack_fetch, m16): rows 32 ob + 16 s2 + (lane & 15), slot phi of
+    // the k-block = register t, lane half h of the 32x32 form the encoding blocks are made in
+    const int phi = m16_slot(lane >> 4, jj);
+    const int h = (phi >> 2) & 1, t = 4 * (phi >> 3) + (phi & 3);
+    const int brow = 16 * s2 + (lane & 15);
+    const int64_t row = int64_t(ob * 32 + brow) * p.ldw;
     float v = 0.f;
     if (kbpos < p.pre_kb) {
         const int c = pe_col(kbpos * 16 + t, h, p.pre_L);
         if (c >= 0) v = p.W[row + p.pre_col0 + c];
     } else if (kbpos < p.pre_kb + p.hid_kb) {
         if (p.split_row) {
-            const int r = lane & 31;
+            const int r = brow;
             const float wv = p.W[p.hid_col0 + 32 * (kbpos - p.pre_kb) + acc_row(t, h)];
             v = r == 0 ? wv : (r == 1 ? __fsub_rn(wv, float((__bf16)wv)) : 0.f);
         } else {
@@ -192,7 +201,7 @@ __device__ unsigned long long g_bf_stamps[256 * 8 * 128];
 #endif
 
 #define NRF_MFMA_BF16(a, b, c) \
-    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+    __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 // Activation of a finished accumulator block: max(bits, lim) as integers is relu for lim = 0 (negative floats are
 // negative ints) and the identity for lim = INT_MIN, so "relu or not" is a run-time scalar, not another code body.
@@ -223,21 +232,26 @@ struct EpiPack {  // hidden layers: activate + pack block ob of every set into t
 template <int NSETS>
 struct EpiRgb {  // views layer: relu + the rgb head's partial dot products (fp32 weights on the VALU)
     static constexpr int Q = 16 * NSETS;  // one accumulator register (a row pair of the block) per slice
-    const float* rw;  // cst + rgb weights + h * 16
-    float acc[NSETS][3];
-    f32x16 w0, w1, w2;
+    const float* rw;  // cst + rgb weights + g * 8 (m16.h: [c][block][g][8])
+    float acc[NSETS][2][3];   // [set][point half nb][c]
+    float w0[8], w1[8], w2[8];
     __device__ __forceinline__ void begin(int ob) {
-        w0 = *reinterpret_cast<const f32x16*>(rw + ob * 32);
-        w1 = *reinterpret_cast<const f32x16*>(rw + 128 + ob * 32);
-        w2 = *reinterpret_cast<const f32x16*>(rw + 256 + ob * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(rw + ob * 32 + 4 * i);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(rw + 128 + ob * 32 + 4 * i);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(rw + 256 + ob * 32 + 4 * i);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w0[4 * i + t] = a[t], w1[4 * i + t] = b[t], w2[4 * i + t] = c[t];
+        }
     }
     __device__ __forceinline__ void slice(int, const f32x16 (&y)[NSETS], int q) {
-        const int set = q / 16, t = q % 16;
+        const int set = q / 16, t = q % 16, nb = t / 8, k = t % 8;
         const int b = __float_as_int(y[set][t]);
         const float hv = __int_as_float(b > 0 ? b : 0);
-        acc[set][0] = fmaf(w0[t], hv, acc[set][0]);
-        acc[set][1] = fmaf(w1[t], hv, acc[set][1]);
-        acc[set][2] = fmaf(w2[t], hv, acc[set][2]);
+        acc[set][nb][0] = fmaf(w0[k], hv, acc[set][nb][0]);
+        acc[set][nb][1] = fmaf(w1[k], hv, acc[set][nb][1]);
+        acc[set][nb][2] = fmaf(w2[k], hv, acc[set][nb][2]);
     }
 };
 
@@ -272,7 +286,7 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
             if (lane == 0) g_bf_stamps[st.stamp_wave * 128 + st.stamp_base + ob] = t_;
         }
 #endif
-        const f32x16 bias = *reinterpret_cast<const f32x16*>(bias_h + ob * 32);  // srcC of the block's first MFMAs
+        const f32x16 bias = *reinterpret_cast<const f32x16*>(bias_h + ob * 64);  // srcC of the block's first MFMAs ([g][16])
         if (ob > 0) epi.begin(ob - 1);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -319,11 +333,19 @@ __device__ __forceinline__ void bf_layer(BRing& st, int lane, const float* bias_
                             pend.slice(7, acc[1], q);
                     }
                 }
-                const bool first = kb == 0 && s2 == 0;
+                // rows 16 s2 .. + 15 of the block against all 32 k of k-block kb: the accumulators of row half s2, two
+                // point halves per set (x[0], x[1]); the k-block's first step of each row half starts from the bias
 #pragma unroll
                 for (int set = 0; set < NSETS; ++set) {
-                    const u32x4 x = kb < NPRE ? pre[set][kb][s2] : (kb < NPRE + NHID ? Xin[set][kb - NPRE][s2] : post[set][s2]);
-                    acc[ob & 1][set] = NRF_MFMA_BF16(w, x, first ? bias : acc[ob & 1][set]);
+                    const u32x4* x = kb < NPRE ? pre[set][kb] : (kb < NPRE + NHID ? Xin[set][kb - NPRE] : post[set]);
+                    const f32x16& src = kb == 0 ? bias : acc[ob & 1][set];
+                    f32x4 ya, yb;
+                    if (s2) blk16_get<1>(src, ya, yb);
+                    else blk16_get<0>(src, ya, yb);
+                    ya = NRF_MFMA_BF16(w, x[0], ya);
+                    yb = NRF_MFMA_BF16(w, x[1], yb);
+                    if (s2) blk16_put<1>(acc[ob & 1][set], ya, yb);
+                    else blk16_put<0>(acc[ob & 1][set], ya, yb);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // keep the slices where they are: one step = one scheduling region
             }
@@ -358,21 +380,22 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, h = lane >> 5;
+    const int j = lane & 31, h = lane >> 5, g = lane >> 4;
     {
         const float4* src = reinterpret_cast<const float4*>(packed + kBSmallFloatOff * 4);
         float4* dst = reinterpret_cast<float4*>(smem + kBLdsConstOff);
-        for (int i = threadIdx.x; i < kSmallFloats / 4; i += 64 * WAVES) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kS16Floats / 4; i += 64 * WAVES) dst[i] = src[i];
     }
     __syncthreads();
-    {   // the alpha block's accumulator initialiser, [h][16] like every bias block: alpha_b in row 0, zeros elsewhere.  It
-        // takes the place of the head's fp32 weights in LDS, which this kernel no longer reads.
-        float* ab = reinterpret_cast<float*>(smem + kBLdsConstOff) + (kOffAlphaW - kOffBias);
-        if (threadIdx.x < 32) ab[threadIdx.x] = threadIdx.x == 0 ? ab[kOffAlphaB - kOffAlphaW] : 0.f;
+    {   // the alpha block's accumulator initialiser, [g][16] like every bias block: alpha_b in row 0 (group 0, registers 0
+        // and 8: the two point halves), zeros elsewhere.  It takes the place of the head's fp32 weights in LDS, which this
+        // kernel does not read.
+        float* ab = reinterpret_cast<float*>(smem + kBLdsConstOff) + kS16AlphaW;
+        if (threadIdx.x < 64) ab[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 8) ? ab[kS16AlphaB - kS16AlphaW] : 0.f;
     }
     __syncthreads();
     const float* cst = reinterpret_cast<const float*>(smem + kBLdsConstOff);
-    const float* bias_h = cst + h * 16;
+    const float* bias_h = cst + g * 16;   // this lane group's 16 of a block's [g][16] initialisers
 
     BRing st;
     br_start<PW>(st, packed, smem, wave, lane);
@@ -398,9 +421,9 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
                 f32x16 enc[2], denc[1];
                 encode_pe_doubling<10>(px, py, pz, h, enc);
                 encode_pe_doubling<4>(dx, dy, dz, h, denc);
-                pack_tile(enc[0], pe[set][0]);
-                pack_tile(enc[1], pe[set][1]);
-                pack_tile(denc[0], dpe[set]);
+                pack_tile(to_m16(enc[0]), pe[set][0]);   // made in the 32x32 form, handed over (m16.h)
+                pack_tile(to_m16(enc[1]), pe[set][1]);
+                pack_tile(to_m16(denc[0]), dpe[set]);
             }
         } else {
             const int64_t ray = tile / tiles_per_ray;
@@ -417,12 +440,12 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
                 const float pz = __fadd_rn(oz, __fmul_rn(zz, dz));
                 f32x16 enc[2];
                 encode_pe_doubling<10>(px, py, pz, h, enc);
-                pack_tile(enc[0], pe[set][0]);
-                pack_tile(enc[1], pe[set][1]);
+                pack_tile(to_m16(enc[0]), pe[set][0]);
+                pack_tile(to_m16(enc[1]), pe[set][1]);
             }
             f32x16 denc[1];
             encode_pe_doubling<4>(dx, dy, dz, h, denc);
-            pack_tile(denc[0], dpe[0]);  // all sets are samples of the same ray
+            pack_tile(to_m16(denc[0]), dpe[0]);  // all sets are samples of the same ray
 #pragma unroll
             for (int set = 1; set < NSETS; ++set) dpe[set][0] = dpe[0][0], dpe[set][1] = dpe[0][1];
         }
@@ -437,7 +460,7 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
         // pts1..7 + feature as 4 pairs (XA -> XB -> XA); pair 2 starts with the skip layer, the last layer of pair 3
         // is feature_linear (no activation)
         for (int p = 0; p < 4; ++p) {
-            const float* b0 = bias_h + (2 * p + 1) * 256;
+            const float* b0 = bias_h + (2 * p + 1) * 512;
 #ifdef BF_STAMP
             st.stamp_base = stamp_tile ? 16 + 20 * p : -1;
 #endif
@@ -451,7 +474,7 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
             st.stamp_base = stamp_tile ? 26 + 20 * p : -1;
 #endif
             toA.lim = p == 3 ? kActNone : kActRelu;                                                               // feature_linear: no activation
-            bf_layer<NSETS, 8, 0, 8, 0, kBStepsHidden, true>(st, lane, b0 + 256, nullptr, XB, nullptr, toA, acc, toB);
+            bf_layer<NSETS, 8, 0, 8, 0, kBStepsHidden, true>(st, lane, b0 + 512, nullptr, XB, nullptr, toA, acc, toB);
             BF_STAMP_AT(4 + 2 * p);
 #ifdef BF_STAMP
             st.stamp_base = -1;
@@ -470,29 +493,38 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
             for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+a"(XB[set][kb][s2]));
-        bf_layer<NSETS, 1, 0, 8, 0, kBStepsAlphaPad, true>(st, lane, cst + (kOffAlphaW - kOffBias) + h * 16, nullptr, XB, nullptr, toB, acc, toA);
-        float sigma[NSETS];
+        bf_layer<NSETS, 1, 0, 8, 0, kBStepsAlphaPad, true>(st, lane, cst + kS16AlphaW + g * 16, nullptr, XB, nullptr, toB, acc, toA);
+        // rows 0 and 1 of the block = registers 0, 1 (points c) and 8, 9 (points 16 + c) of lane group 0
+        float sigma[NSETS][2];
 #pragma unroll
         for (int set = 0; set < NSETS; ++set) {
-            sigma[set] = acc[0][set][0] + acc[0][set][1];
-            asm volatile("" : "+v"(sigma[set]));   // pinned here: sunk behind the views layer it would keep the block alive across it
+            sigma[set][0] = acc[0][set][0] + acc[0][set][1];
+            sigma[set][1] = acc[0][set][8] + acc[0][set][9];
+            asm volatile("" : "+v"(sigma[set][0]), "+v"(sigma[set][1]));   // pinned here: sunk behind the views layer it would keep the block alive across it
         }
         BF_STAMP_AT(11);
         // views_linears.0 on cat([feature (XA, no activation), dir PE]) -> 128, relu, rgb_linear
         EpiRgb<NSETS> er;
-        er.rw = cst + (kOffRgbW - kOffBias) + h * 16;
+        er.rw = cst + kS16RgbW + g * 8;
 #pragma unroll
-        for (int set = 0; set < NSETS; ++set) er.acc[set][0] = er.acc[set][1] = er.acc[set][2] = 0.f;
-        bf_layer<NSETS, 4, 0, 8, 1, kBStepsViewsPad, false>(st, lane, bias_h + 9 * 256, nullptr, XA, dpe, er, acc, toA);
+        for (int set = 0; set < NSETS; ++set)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) er.acc[set][0][c] = er.acc[set][1][c] = 0.f;
+        bf_layer<NSETS, 4, 0, 8, 1, kBStepsViewsPad, false>(st, lane, bias_h + 9 * 512, nullptr, XA, dpe, er, acc, toA);
         bf_finish<NSETS, 4>(er, acc);
         BF_STAMP_AT(12);
-        const float* rb = cst + (kOffRgbB - kOffBias);
+        const float* rb = cst + kS16RgbB;
+        const bool odd = (g & 1) != 0;
 #pragma unroll
         for (int set = 0; set < NSETS; ++set) {
-            float r = er.acc[set][0], g = er.acc[set][1], b = er.acc[set][2];
-            r += __shfl_xor(r, 32), g += __shfl_xor(g, 32), b += __shfl_xor(b, 32);
-            const int64_t dst = tile * TP + 32 * set + j;   // (sigma is complete, bias included, in lane half 0)
-            if (h == 0 && valid && (!POINTS || dst < n_points)) raw[dst] = make_float4(r + rb[0], g + rb[1], b + rb[2], sigma[set]);
+            // lane l < 32 stores point l of the set: group 0 holds points c, group 1 takes points 16 + c (m16.h: add_groups);
+            // sigma is complete, bias included, in group 0: its second half goes to group 1
+            const float r = add_groups(er.acc[set][0][0], er.acc[set][1][0], odd), gr = add_groups(er.acc[set][0][1], er.acc[set][1][1], odd);
+            const float b = add_groups(er.acc[set][0][2], er.acc[set][1][2], odd);
+            const float s1 = __shfl_xor(sigma[set][1], 16);
+            const int64_t dst = tile * TP + 32 * set + j;
+            if (lane < 32 && valid && (!POINTS || dst < n_points))
+                raw[dst] = make_float4(r + rb[0], gr + rb[1], b + rb[2], odd ? s1 : sigma[set][0]);
         }
         BF_STAMP_AT(13);
     }
@@ -501,7 +533,7 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
 
 }  // namespace
 
-NRF_EXPORT int64_t nrf_packed_bf16_bytes(void) { return kBSmallFloatOff * 4 + int64_t(kSmallFloats) * 4; }
+NRF_EXPORT int64_t nrf_packed_bf16_bytes(void) { return kBSmallFloatOff * 4 + int64_t(kS16Floats) * 4; }
 
 NRF_EXPORT int nrf_pack_weights_bf16(const float* const* w, const float* const* b, void* packed, nrf_stream_t stream_) {
     if (!w || !b || !packed) return NRF_ERR_NULL;
@@ -527,17 +559,12 @@ NRF_EXPORT int nrf_pack_weights_bf16(const float* const* w, const float* const* 
     launch(BPackLayer{w[8], nullptr, 256, 8, 0, 8, 0, 0, 0, 0, 0, 0, 0}, kBLayerStep[8]);     // feature_linear
     launch(BPackLayer{w[9], nullptr, 256, 1, 0, 8, 0, 0, 0, 0, 0, 0, 1}, kBAlphaStep);        // alpha_linear: one block, two-term weight
     launch(BPackLayer{w[10], nullptr, 283, 4, 0, 8, 1, 0, 4, 0, 0, 256, 0}, kBLayerStep[9]);  // views_linears.0
-    PackSmall s;
-    for (int l = 0; l < 8; ++l) s.bias[l] = b[l];
-    s.bias[8] = b[8];
+    PackSmall16 s;
+    for (int l = 0; l < 9; ++l) s.bias[l] = b[l];
     s.bias[9] = b[10];
-    s.alpha_w = w[9];
-    s.alpha_b = b[9];
-    s.rgb_w = w[11];
-    s.rgb_b = b[11];
-    s.packed = static_cast<float*>(packed);
-    s.small_shift = kBSmallFloatOff - kOffBias;
-    pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
+    s.alpha_w = w[9], s.alpha_b = b[9], s.rgb_w = w[11], s.rgb_b = b[11];
+    s.dst = static_cast<float*>(packed) + kBSmallFloatOff;
+    pack_small16_kernel<<<(kS16Floats + 255) / 256, 256, 0, stream>>>(s);
     return nrf_launch_status();
 }
 

@@ -110,6 +110,12 @@ constexpr int64_t kBwdPackedFloats = int64_t(kBwdSteps + kPrefetch) * kStepFloat
 // row of a 32x32 MFMA accumulator held in register t of lane-half h
 __host__ __device__ constexpr int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
+// 16x16x32 form (m16.h): which of a 32-feature block's slots sits at element jj (0..7) of lane group g (0..3) of a B / A
+// fragment.  A wave holds a block of a layer's output as four 16 x 16 accumulators (two 16-row halves mh x two 16-point
+// halves nb); register 8 nb + 4 mh + r of lane (c, g) is feature 16 mh + 4 g + r of point 16 nb + c, and the eight
+// registers of one nb are, in order, the lane's eight k-values of the next layer's B fragment.
+__host__ __device__ constexpr int m16_slot(int g, int jj) { return 16 * (jj >> 2) + 4 * g + (jj & 3); }
+
 // Kernel PE slot n of lane-half h -> column of the reference encoding
 // cat([x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]) (3 wide each), or -1.
 // Half 0 holds the sin terms, half 1 the cos terms; slots 3L, 3L+1 hold the raw input.

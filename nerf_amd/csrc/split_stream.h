@@ -36,11 +36,6 @@ struct XPackLayer {
     int m16;          // A fragments of v_mfma_*_16x16x32 (mlp_bf16x3.hip, M16): the step at the same stream position holds rows
                       // 32 ob + 16 s2 + (lane & 15) and, in lane group g = lane >> 4, the 8 k of feature slots m16_slot(g, jj)
 };
-// 16x16x32 form: which of a 32-feature block's slots sits at element jj (0..7) of lane group g (0..3) of a B / A fragment.
-// A wave holds a block of a layer's output as four 16 x 16 accumulators (two 16-row halves mh x two 16-point halves nb);
-// register 8 nb + 4 mh + r of lane (c, g) is feature 16 mh + 4 g + r of point 16 nb + c, and the eight registers of one nb
-// are, in order, the lane's eight k-values of the next layer's B fragment.
-__host__ __device__ constexpr int m16_slot(int g, int jj) { return 16 * (jj >> 2) + 4 * g + (jj & 3); }
 __device__ __forceinline__ int xpack_total(const XPackLayer& p) { return p.nob * (p.pre_kb + p.hid_kb + p.post_kb) * 2 * 512; }
 __device__ __forceinline__ float xpack_fetch(const XPackLayer& p, int idx, int& step, int& lane, int& jj) {
     const int nkb = p.pre_kb + p.hid_kb + p.post_kb;

@@ -85,7 +85,7 @@ def test_render_bf16_end_to_end_vs_fp32_reference(golden, dev, name):
 def test_bf16_argument_checks(dev):
     from nerf_amd import _lib
     L = _lib.lib()
-    assert L.nrf_packed_bf16_bytes() == 1216 * 1024 + 3104 * 4      # 38 chunks of 32 KiB (alpha_linear has its own) + the fp32 small block
+    assert L.nrf_packed_bf16_bytes() == 1216 * 1024 + 5536 * 4      # 38 chunks of 32 KiB (alpha_linear has its own) + the fp32 small block of the 16x16x32 form
     assert L.nrf_mlp_forward_rays_bf16(None, None, None, None, 0, 4, 96, None, None) == -2     # 96 % 64 != 0
     assert L.nrf_mlp_forward_rays_bf16(None, None, None, None, 0, 0, 64, None, None) == 0      # empty batch
     assert L.nrf_mlp_forward_rays_bf16(None, None, None, None, 0, 4, 64, None, None) == -1
