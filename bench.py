@@ -16,7 +16,7 @@ split in contiguous slices over the ranks and one all_gather assembles the frame
 value = rays of the frame / max-over-ranks time per frame (strong scaling, the metric's "ms per
 800x800 frame at 1/2/4/8 MI355X"); the one-view-per-rank rate is carried as `weak_scaling`.
 
-The MLP of the default run is mlp_bf16x3_kernel: the reference's fp32 arithmetic (BASELINE configs[1] "fp32",
+The MLP of the default run is mlp_bf16x3_m16_kernel: the reference's fp32 arithmetic (BASELINE configs[1] "fp32",
 src/models/nerf/network.py:190) -- fp32 in, fp32 out, fp32 accumulate, every fp32 operand carried EXACTLY as three bf16
 terms (3 x 8 = 24 significand bits) and each product as six bf16 MFMAs -- and `dtype` names it.  `--dtype fp32` runs the
 fp32 MFMA kernel (also 24-bit operands); `--dtype fp16x2` is the narrower form (two fp16 terms = 22 significand bits,
@@ -62,8 +62,8 @@ DTYPE_LABEL = {"fp32": "f32", "bf16": "bf16",
                "bf16x3": "bf16x3 (f32 operands as 3 bf16 terms, f32 accumulate; f32 elsewhere)",
                "fp16x2": "fp16x2 (f32 operands as 2 fp16 terms = 22 significand bits, f32 accumulate; f32 elsewhere)"}
 MLP_KERNEL = {"fp32": "mlp_fwd_kernel<false> (fused points + PE + 8x256 MLP, fp32 MFMA)",
-              "bf16": "mlp_bf16_kernel (fused points + PE + 8x256 MLP, bf16 MFMA)",
-              "bf16x3": "mlp_bf16x3_kernel (fused points + PE + 8x256 MLP, 6 bf16 MFMAs per fp32 product; peak = bf16 peak / 6)",
+              "bf16": "mlp_bf16_kernel (fused points + PE + 8x256 MLP, bf16 MFMA 16x16x32)",
+              "bf16x3": "mlp_bf16x3_m16_kernel (fused points + PE + 8x256 MLP, 6 bf16 MFMAs 16x16x32 per fp32 product; peak = bf16 peak / 6)",
               "fp16x2": "mlp_fp16x2_kernel (fused points + PE + 8x256 MLP, 3 fp16 MFMAs per fp32 product; peak = fp16 peak / 3)"}
 
 

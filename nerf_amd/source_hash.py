@@ -14,8 +14,8 @@ _COMMON = ("nrf_common.h", "mlp_chain.h")
 # kernel family -> the sources its code is generated from (beyond the common headers)
 SOURCES = {
     "fp32": ("mlp_fp32.hip",),
-    "bf16": ("mlp_bf16.hip",),
-    "bf16x3": ("mlp_bf16x3.hip", "split3.h", "split_stream.h"),
+    "bf16": ("mlp_bf16.hip", "m16.h"),
+    "bf16x3": ("mlp_bf16x3.hip", "split3.h", "split_stream.h", "m16.h"),
     "fp16x2": ("mlp_fp16x2.hip", "split2h.h", "split_stream.h"),
     "composite": ("composite.hip",),
     "kilo": ("kilo.hip", "kilo_common.h", "split2h.h", "split3.h"),

@@ -3,7 +3,7 @@
 # traffic / counter record carries the hash of the kernel sources in the tree, nerf_amd/source_hash.py).
 set -e
 cd "$(dirname "$0")/.."
-declare -A KERNEL=([bf16x3]=mlp_bf16x3_kernel [bf16]=mlp_bf16_kernel [fp16x2]=mlp_fp16x2_kernel [fp32]=mlp_fwd_kernel)
+declare -A KERNEL=([bf16x3]=mlp_bf16x3_m16_kernel [bf16]=mlp_bf16_kernel [fp16x2]=mlp_fp16x2_kernel [fp32]=mlp_fwd_kernel)
 for dt in bf16x3 bf16 fp16x2 fp32; do
   if [ $dt = bf16x3 ]; then extra=profiles/r03_composite_traffic_pmc.json; else extra=; fi
   python3 tools/bench_traffic_digest.py gpurun_out/r3_traffic_$dt ${KERNEL[$dt]} $dt $extra > profiles/r03_${dt}_traffic_pmc.json

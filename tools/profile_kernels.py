@@ -81,7 +81,7 @@ if a.only == "bf16":        # mlp_bf16_kernel, coarse + fine launch per rep
     torch.cuda.synchronize()
     print("done bf16")
     sys.exit(0)
-if a.only == "bf16x3":      # mlp_bf16x3_kernel, coarse + fine launch per rep
+if a.only == "bf16x3":      # mlp_bf16x3_m16_kernel, coarse + fine launch per rep
     xc, xf = ops.pack_state_dict_bf16x3(sd, "model", dev), ops.pack_state_dict_bf16x3(sd, "model_fine", dev)
     for _ in range(a.reps + 1):
         ops.mlp_forward_rays_bf16x3(xc, o, d, bins)
