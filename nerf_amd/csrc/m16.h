@@ -29,6 +29,16 @@ __device__ __forceinline__ void blk16_get(const Blk16& y, f32x4& a, f32x4& b) { 
 template <int MH>
 __device__ __forceinline__ void blk16_put(Blk16& y, const f32x4& a, const f32x4& b) { blk16_put<MH>(y.v, a, b); }
 
+template <class T> struct is_blk16 { static constexpr bool value = false; };
+template <> struct is_blk16<Blk16> { static constexpr bool value = true; };
+// where register t of a block's lane sits inside the block's saved rows ([row][32 points] floats), relative to the lane's
+// base -- 32x32 form: lane (j, h), base 4 h * 32 + j, row acc_row(t, 0); 16x16x32 form: lane (c, g), base 4 g * 32 + c,
+// row 16 mh + r and point half nb of t = 8 nb + 4 mh + r
+template <bool M16>
+__host__ __device__ constexpr int saved_row_off(int t) {
+    return M16 ? (16 * ((t >> 2) & 1) + (t & 3)) * 32 + 16 * (t >> 3) : ((t & 3) + 8 * (t >> 2)) * 32;
+}
+
 // the small fp32 block of the 16x16x32 stream, in floats from its start
 constexpr int kS16AlphaW = 9 * 512 + 256;         // biases [layer 0..9][block][g][16] before it (views_linears: 4 blocks)
 constexpr int kS16AlphaB = kS16AlphaW + 256;      // alpha weights [block][g][8]
@@ -81,6 +91,29 @@ __attribute__((unused)) __device__ __forceinline__ f32x16 to_m16(const f32x16& e
             r[8 + 4 * mh + rr] = __uint_as_float(s16[1]);
         }
     return r;
+}
+// A block's 16 relu-sign bits per lane travel in memory in the 32x32 form's order (bit t of lane (j, h): slot acc_row(t, h)
+// of point j), whichever form wrote or reads them: the bit-level inverse of to_m16, nibble by nibble (bits 4 mh .. + 3
+// and 8 + 4 mh .. + 3 of the 16x16x32 word are one register quartet of each point half).
+__attribute__((unused)) __device__ __forceinline__ unsigned m16_mask_to_old(unsigned n) {
+    unsigned o = 0;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        const auto s16 = __builtin_amdgcn_permlane16_swap((n >> (4 * mh)) & 0xfu, (n >> (8 + 4 * mh)) & 0xfu, false, false);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(s16[0], s16[1], false, false);
+        o |= (s32[0] << (8 * mh)) | (s32[1] << (8 * mh + 4));
+    }
+    return o;
+}
+__attribute__((unused)) __device__ __forceinline__ unsigned m16_mask_from_old(unsigned o) {
+    unsigned n = 0;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        const auto s32 = __builtin_amdgcn_permlane32_swap((o >> (8 * mh)) & 0xfu, (o >> (8 * mh + 4)) & 0xfu, false, false);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(s32[0], s32[1], false, false);
+        n |= (s16[0] << (4 * mh)) | (s16[1] << (8 + 4 * mh));
+    }
+    return n;
 }
 // Head sums of the 16x16x32 form: a lane holds partial sums of TWO points (v0: point c, v1: point 16 + c) over its group's
 // features.  Returns, in even groups, the sum of v0 over the four groups and in odd groups that of v1 (lane l < 32 then

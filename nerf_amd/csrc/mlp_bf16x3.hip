@@ -15,7 +15,6 @@
 // Heads (alpha 256->1, rgb 128->3) are fp32 VALU dot products on the fp32 accumulators, as in the fp32 kernel.
 #include "split_stream.h"
 #include "split3.h"
-#include "m16.h"
 
 
 namespace {
@@ -203,7 +202,7 @@ struct OpIn : OpInBase {
             const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
             a = __int_as_float(b0 > lim ? b0 : lim), b = __int_as_float(b1 > lim ? b1 : lim);
         }
-        keep<MODE>(blk, q, a, b);
+        keep<MODE, false, is_blk16<YT>::value>(blk, q, a, b);
     }
     template <int MODE, class YT>
     __device__ __forceinline__ void sub(const YT& y, u32x4 (&x)[2][3], int blk, int q, int phase) {
@@ -475,7 +474,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(const char* __restri
 #define NRF_MFMA_X16(a, b, c) \
     __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
+// The pack holds the 16x16x32 stream and its small block; an A/B build with -DX3_FWD_32X32 runs the 32x32x16 kernels and puts
+// their stream and small block in front.
+#ifdef X3_FWD_32X32
 constexpr int64_t kX16StreamOff = (kXSmallFloatOff + kSmallFloats) * 4;                  // bytes from the start of the pack
+#else
+constexpr int64_t kX16StreamOff = 0;
+#endif
 constexpr int64_t kX16SmallOff = kX16StreamOff + int64_t(kXStreamSteps) * kXStepBytes;
 constexpr int64_t kXPackedBytes = kX16SmallOff + int64_t(kS16Floats) * 4;
 static_assert(kX16StreamOff % 16 == 0 && kX16SmallOff % 16 == 0, "LDS-DMA and float4 alignment");
@@ -533,14 +538,14 @@ __device__ __forceinline__ void x16_pe_layer(XRingS& st, int lane, const float* 
     }
 }
 
-// x3_hidden_layer in the 16x16x32 form (forward only)
-template <int NOB, int NPOST, int NHID = 8>
+// x3_hidden_layer in the 16x16x32 form
+template <int NOB, int NPOST, int MODE, int NHID = 8>
 __device__ __forceinline__ void x16_hidden_layer(XRingS& st, int lane, const float* bias_g, u32x4 (*X)[2][3],
                                                  const u32x4 (*post)[2][3], Blk16* Y, Blk16& Z, OpIn& op) {
     constexpr int NKB = NHID + NPOST;
     static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
 #pragma unroll
-    for (int q = 0; q < 8; ++q) op.template pair<kOpFwd>(Y[0], X[0], 0, q);
+    for (int q = 0; q < 8; ++q) op.template pair<MODE>(Y[0], X[0], 0, q);
     Y[0] = bias16(bias_g, 0);
     Z = bias16(bias_g, 1);
 #pragma unroll
@@ -554,7 +559,7 @@ __device__ __forceinline__ void x16_hidden_layer(XRingS& st, int lane, const flo
                 const int g = b * 2 + s2;
                 auto hook = [&](int m) {
                     const int n = g * 6 + m;
-                    if (make) op.template sub<kOpFwd>(Y[kb + 1], X[kb + 1], kb + 1, n / 3, n % 3);
+                    if (make) op.template sub<MODE>(Y[kb + 1], X[kb + 1], kb + 1, n / 3, n % 3);
                     if (kb == NKB - 1 && g == 3 && m == 0 && NOB > 2) Y[2] = bias16(bias_g, 2);
                 };
                 Blk16& y = b == 0 ? Y[0] : Z;
@@ -576,12 +581,16 @@ __device__ __forceinline__ void x16_hidden_layer(XRingS& st, int lane, const flo
     }
 }
 
-// The kernel above (SAVE = false) in the 16x16x32 form.  `stream` / `small16`: the second half of the pack.
+// The kernel above in the 16x16x32 form.  `stream` / `small16`: the second half of the pack.  SAVE: the saved rows and
+// sign words land in memory exactly as the 32x32 form writes them (rows are [row][32 points] whoever stores them; the
+// sign words are re-ordered before their store, m16.h), so every backward kernel reads them unchanged.
+template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void mlp_bf16x3_m16_kernel(const char* __restrict__ stream, const float* __restrict__ small16,
                                                                 const float* __restrict__ a0, const float* __restrict__ a1,
                                                                 const float* __restrict__ zbuf, int64_t z_stride, int tiles_per_ray,
                                                                 int rays_mode, int64_t n_points, int64_t n_groups,
-                                                                float4* __restrict__ raw) {
+                                                                float4* __restrict__ raw, float* __restrict__ acts,
+                                                                unsigned* __restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -622,12 +631,27 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_m16_kernel(const char* __re
             dx = a1[pidx * 3 + 0], dy = a1[pidx * 3 + 1], dz = a1[pidx * 3 + 2];
         }
         u32x4 pe[2][2][3], dpe[1][2][3];
-        split_block_x3(sel, to_m16(encode_block<10, 0>(px, py, pz, h)), pe[0]);
-        split_block_x3(sel, to_m16(encode_block<10, 1>(px, py, pz, h)), pe[1]);
-        split_block_x3(sel, to_m16(encode_block<4, 0>(dx, dy, dz, h)), dpe[0]);
+        float* arow = nullptr;     // this lane's base inside the tile's saved rows: 4 g * 32 + c (m16.h: saved_row_off)
+        unsigned* mrow = nullptr;
+        {
+            const f32x16 e0 = encode_block<10, 0>(px, py, pz, h), e1 = encode_block<10, 1>(px, py, pz, h);
+            const f32x16 ed = encode_block<4, 0>(dx, dy, dz, h);
+            if (SAVE) {   // the encodings are made in the 32x32 form and saved from it
+                float* arow32 = acts + tile * (int64_t(kActRows) * 32) + 4 * h * 32 + j;
+                store_block(arow32 + kActPe * 32, 0, e0);
+                store_block(arow32 + kActPe * 32, 1, e1);
+                store_block(arow32 + kActDpe * 32, 0, ed);
+                arow = acts + tile * (int64_t(kActRows) * 32) + 4 * g * 32 + (lane & 15);
+                mrow = masks + tile * (kMaskLayers * 4 * 64) + lane;
+            }
+            split_block_x3(sel, to_m16(e0), pe[0]);
+            split_block_x3(sel, to_m16(e1), pe[1]);
+            split_block_x3(sel, to_m16(ed), dpe[0]);
+        }
 
         u32x4 X[8][2][3];
         Blk16 Y[8], Z;
+        constexpr int MODE = SAVE ? kOpFwdSave : kOpFwd;
         OpIn op{op_in(kActRelu, nullptr), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
         float sig0 = 0.f, sig1 = 0.f;
         for (int li = 1; li <= 8; ++li) {
@@ -646,14 +670,36 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_m16_kernel(const char* __re
                     }
                 }
             }
-            x16_hidden_layer<8, 0>(st, lane, bias_g + li * 512, X, nullptr, Y, Z, op);
+            if (SAVE) {   // the layer's input h_{li-1} = relu(Y) and its signs (mask li - 1)
+                op.save = arow + (kActH + (li - 1) * 256) * 32;
+                op.msave = mrow + (li - 1) * 4 * 64;
+            }
+            x16_hidden_layer<8, 0, MODE>(st, lane, bias_g + li * 512, X, nullptr, Y, Z, op);
         }
         asm volatile("" : "+v"(sig0), "+v"(sig1));   // keep the head where it is (see mlp_bf16.hip)
-        OpIn op_views{op_in(kActNone, nullptr), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
-        x16_hidden_layer<4, 1>(st, lane, bias_g + 9 * 512, X, dpe, Y, Z, op_views);   // views_linears.0
+        // feature -> views: no activation (saved as it is, no mask)
+        OpIn op_views{op_in(kActNone, nullptr, SAVE ? arow + kActFeat * 32 : nullptr), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
+        x16_hidden_layer<4, 1, MODE>(st, lane, bias_g + 9 * 512, X, dpe, Y, Z, op_views);   // views_linears.0
         float c0[3] = {0.f, 0.f, 0.f}, c1[3] = {0.f, 0.f, 0.f};
         {
             const float* rw = cst + kS16RgbW + g * 8;
+            if (SAVE) {   // hv = relu(views output): rows and signs (mask 8), as OpFwdSave<true> does in the 32x32 form
+                unsigned prev = 0u;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int bv = __float_as_int(Y[kb][t]);
+                        const float hv = __int_as_float(bv > 0 ? bv : 0);
+                        save_row(arow + (kActHv + 32 * kb) * 32 + saved_row_off<true>(t), hv);
+                        bits |= (hv > 0.f ? 1u : 0u) << t;
+                    }
+                    const unsigned w = m16_mask_to_old(bits);
+                    if (kb & 1) mrow[(8 * 4 + (kb >> 1)) * 64] = prev | (w << 16);
+                    else prev = w;
+                }
+            }
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -790,21 +836,30 @@ int launch_x3(const void* packed, const float* a0, const float* a1, const float*
     }
     const unsigned grid = unsigned(groups < cus ? groups : cus);
     nrf_launch_begin();
-    if (!acts) {   // inference: the 16x16x32 form, on the second stream of the pack
+#ifndef X3_FWD_32X32   // (A/B switch: the 32x32x16 kernels on the first stream of the pack)
+    {   // the 16x16x32 form, on the second stream of the pack
         static bool attr16_set[64] = {};
         if (dev >= 0 && dev < 64 && !attr16_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16x3_m16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16x3_m16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kX16LdsBytes) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bf16x3_m16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kX16LdsBytes) != hipSuccess)
                 return NRF_ERR_LAUNCH;
             attr16_set[dev] = true;
         }
         const char* base = static_cast<const char*>(packed);
-        mlp_bf16x3_m16_kernel<<<dim3(grid), 256, kX16LdsBytes, stream>>>(base + kX16StreamOff,
-                                                                        reinterpret_cast<const float*>(base + kX16SmallOff), a0, a1, z,
-                                                                        z_stride, tiles_per_ray, rays_mode, n_points, groups,
-                                                                        reinterpret_cast<float4*>(raw));
+        const float* small16 = reinterpret_cast<const float*>(base + kX16SmallOff);
+        if (acts)
+            mlp_bf16x3_m16_kernel<true><<<dim3(grid), 256, kX16LdsBytes, stream>>>(base + kX16StreamOff, small16, a0, a1, z, z_stride,
+                                                                                  tiles_per_ray, rays_mode, n_points, groups,
+                                                                                  reinterpret_cast<float4*>(raw), acts, masks);
+        else
+            mlp_bf16x3_m16_kernel<false><<<dim3(grid), 256, kX16LdsBytes, stream>>>(base + kX16StreamOff, small16, a0, a1, z, z_stride,
+                                                                                   tiles_per_ray, rays_mode, n_points, groups,
+                                                                                   reinterpret_cast<float4*>(raw), nullptr, nullptr);
         return nrf_launch_status();
     }
+#endif
     if (acts)
         mlp_bf16x3_kernel<true><<<dim3(grid), 256, kXLdsBytes, stream>>>(static_cast<const char*>(packed), a0, a1, z, z_stride,
                                                                          tiles_per_ray, rays_mode, n_points, groups,
@@ -866,7 +921,6 @@ NRF_EXPORT int nrf_pack_weights_transposed_bf16x3(const float* const* w, void* p
 }
 
 
-// the pack: [32x32x16 stream | its small block] for the training forward, [16x16x32 stream | its small block] for inference
 NRF_EXPORT int64_t nrf_packed_bf16x3_bytes(void) { return kXPackedBytes; }
 
 NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const* b, void* packed, nrf_stream_t stream_) {
@@ -885,13 +939,15 @@ NRF_EXPORT int nrf_pack_weights_bf16x3(const float* const* w, const float* const
         batch.l[n_batch++] = p;
         max_total = total > max_total ? total : max_total;
     };
+#ifdef X3_FWD_32X32
     xpack_forward_layers(w, launch);
     xpack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch);
     const PackSmall s = xpack_small(w, b, packed, kXSmallFloatOff);
     pack_small_kernel<<<(kSmallFloats + 255) / 256, 256, 0, stream>>>(s, 0, 0);
-    // the same layers as A fragments of the 16x16x32 form
-    base = reinterpret_cast<unsigned short*>(static_cast<char*>(packed) + kX16StreamOff);
     n_batch = 0;
+#endif
+    // the layers as A fragments of the 16x16x32 form (split_stream.h: xpack_fetch, m16)
+    base = reinterpret_cast<unsigned short*>(static_cast<char*>(packed) + kX16StreamOff);
     xpack_forward_layers(w, launch, 2, 1);
     xpack_layers_kernel<<<dim3((max_total + 255) / 256, n_batch), 256, 0, stream>>>(batch);
     PackSmall16 s16;

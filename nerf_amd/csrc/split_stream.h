@@ -2,7 +2,7 @@
 // terms): the order of the weight stream in k16-steps, the packer's source lookup, and the input op of a hidden-type
 // layer up to the point where the operand is split.
 #pragma once
-#include "mlp_chain.h"
+#include "m16.h"
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -113,7 +113,7 @@ struct OpInBase {
     unsigned m[4];
     float dsig;
     float kscale;      // SCALED stores (the fp16x2 backward chain runs at a power-of-two loss scale): saved = value * kscale
-    template <int MODE, bool SCALED = false>
+    template <int MODE, bool SCALED = false, bool M16 = false>   // M16: the lane holds the block in the 16x16x32 form (m16.h)
     __device__ __forceinline__ void keep(int blk, int q, float a, float b) {
         if (MODE == kOpFwd) return;
 #ifdef NRF_ABL_NOKEEP   // timing only (tools/debug/lib_ab.sh)
@@ -126,15 +126,16 @@ struct OpInBase {
         *reinterpret_cast<float2*>(save + (32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32 + (threadIdx.x & 31)) =
             make_float2(SCALED ? a * kscale : a, SCALED ? b * kscale : b);
 #else
-        save_row(save + (32 * blk + (t0 & 3) + 8 * (t0 >> 2)) * 32, SCALED ? a * kscale : a);
-        save_row(save + (32 * blk + (t1 & 3) + 8 * (t1 >> 2)) * 32, SCALED ? b * kscale : b);
+        save_row(save + 32 * blk * 32 + saved_row_off<M16>(t0), SCALED ? a * kscale : a);
+        save_row(save + 32 * blk * 32 + saved_row_off<M16>(t1), SCALED ? b * kscale : b);
 #endif
         if (MODE == kOpFwdSave && msave) {
             if (q == 0) mcur = 0u;
             mcur |= ((a > 0.f ? 1u : 0u) << t0) | ((b > 0.f ? 1u : 0u) << t1);   // (as min(bits, 1) << t | mcur: no faster)
             if (q == 7) {
-                if (blk & 1) msave[(blk >> 1) * 64] = mprev | (mcur << 16);
-                else mprev = mcur;
+                const unsigned w = M16 ? m16_mask_to_old(mcur) : mcur;   // the words in memory keep the 32x32 form's bit order
+                if (blk & 1) msave[(blk >> 1) * 64] = mprev | (w << 16);
+                else mprev = w;
             }
         }
     }
@@ -165,7 +166,7 @@ struct OpInBase {
             const int b0 = __float_as_int(y[2 * q]), b1 = __float_as_int(y[2 * q + 1]);
             a = __int_as_float(b0 > lim ? b0 : lim), b = __int_as_float(b1 > lim ? b1 : lim);
         }
-        keep<MODE, SCALED>(blk, q, a, b);
+        keep<MODE, SCALED, is_blk16<YT>::value>(blk, q, a, b);
     }
 };
 __device__ __forceinline__ OpInBase op_in(int lim, const float* aw, float* save = nullptr) {
