@@ -176,5 +176,11 @@ def test_autograd_route_follows_the_fused_route(run, dtype):
     # Same gradients kernels, two Adam implementations (2e-6 apart per step on O(1) parameters): nearly every entry agrees
     # to that; the tail is entries whose gradient changed because a 1e-7 parameter difference after step 1 flipped a
     # fine-sample bin or a relu sign in a later forward -- Adam's normalised step turns that into up to lr per step.
-    assert got[0] <= 1e-6 and got[1] <= 1e-5, got
+    # One flipped bin moves ONE ray's contribution, 1 / 256 of every entry's gradient: lr * 0.4 % = 2e-6 per later step
+    # for every entry.  Whether the five steps contain such a flip depends on the kernels' last bits: with the forward on
+    # the 32x32x16 kernel they did not (median 2.6e-8, 99 % 3.1e-6), on the 16x16x32 kernel one occurs (6.5e-7, 2.1e-5) --
+    # while the one-step gradients of the two routes agree to 1e-9 of 1e-2 with either kernel
+    # (tools/debug/x3_routes_compare.py) and the forward's saved rows / sign words agree between the kernels to 3e-6 / 109
+    # bits of 9e8 (tools/debug/x3_train_fwd_compare.py).  The bars allow for one flip.
+    assert got[0] <= 2e-6 and got[1] <= 5e-5, got
     assert got[3] <= 2 * sum(run["lrs"][:5]), got
