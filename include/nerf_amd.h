@@ -377,6 +377,12 @@ int nrf_occ_bake(const float* packed_teacher, const float* aabb_host, const int*
 int nrf_occ_bake_fp16x2(const void* packed_teacher_h2, const float* aabb_host, const int* res_host, float threshold,
                         int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
                         nrf_stream_t stream);
+/* nrf_occ_bake with the teacher on the bf16x3 kernel (packed_teacher_x3 from nrf_pack_weights_bf16x3): the same
+ * `_evaluate_grid` (volumn_renderer.py:142-232) with every operand carried exactly (24 bits, fp32's range), about twice the
+ * fp32 MFMA kernel's bake rate. */
+int nrf_occ_bake_bf16x3(const void* packed_teacher_x3, const float* aabb_host, const int* res_host, float threshold,
+                        int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
+                        nrf_stream_t stream);
 
 /* The NeRF renderer's own occupancy grid: Renderer._build_occ_grid (src/models/nerf/renderer/volume_renderer.py:156-197).
  * ONE point per voxel at torch.linspace(min, max, res)[i] per axis (:170-178), through `packed` (the network's

@@ -32,7 +32,7 @@ SYMBOLS = (
     "nrf_packed_bf16x3_bytes", "nrf_pack_weights_bf16x3", "nrf_mlp_forward_rays_bf16x3", "nrf_mlp_forward_points_bf16x3",
     "nrf_render_bf16x3",
     "nrf_packed_fp16x2_bytes", "nrf_pack_weights_fp16x2", "nrf_packed_fp16x2_status", "nrf_mlp_forward_rays_fp16x2", "nrf_mlp_forward_points_fp16x2",
-    "nrf_render_fp16x2", "nrf_mlp_forward_rays_train_fp16x2", "nrf_kilo_pack_weights_fp16x2", "nrf_kilo_forward_fp16x2", "nrf_occ_bake_fp16x2", "nrf_packed_bwd_fp16x2_bytes", "nrf_pack_weights_transposed_fp16x2", "nrf_mlp_backward_fp16x2",
+    "nrf_render_fp16x2", "nrf_mlp_forward_rays_train_fp16x2", "nrf_kilo_pack_weights_fp16x2", "nrf_kilo_forward_fp16x2", "nrf_occ_bake_fp16x2", "nrf_occ_bake_bf16x3", "nrf_packed_bwd_fp16x2_bytes", "nrf_pack_weights_transposed_fp16x2", "nrf_mlp_backward_fp16x2",
     "nrf_kilo_dir_table_bytes", "nrf_kilo_encode_dirs", "nrf_kilo_forward_encoded",
     "nrf_kilo_packed_bf16x3_floats", "nrf_kilo_pack_weights_bf16x3", "nrf_kilo_forward_bf16x3",
     "nrf_occ_bricks_bytes", "nrf_occ_pack_bricks", "nrf_kilo_march_count_bricks",
@@ -179,6 +179,8 @@ def lib() -> C.CDLL:
     L.nrf_occ_bake.argtypes = [P, P, P, F, I64, I64, P, P, I64, P]
     L.nrf_occ_bake_fp16x2.restype = INT
     L.nrf_occ_bake_fp16x2.argtypes = [P, P, P, F, I64, I64, P, P, I64, P]
+    L.nrf_occ_bake_bf16x3.restype = INT
+    L.nrf_occ_bake_bf16x3.argtypes = [P, P, P, F, I64, I64, P, P, I64, P]
     L.nrf_occ_bake_vertices_workspace_bytes.restype = I64
     L.nrf_occ_bake_vertices_workspace_bytes.argtypes = [I64]
     L.nrf_occ_bake_vertices.restype = INT

@@ -70,7 +70,7 @@ static int64_t bake_workspace_bytes(int64_t n_cells, int sub) {
 
 static int bake(const float* packed, const float* aabb_host, const int* res_host, float threshold, int64_t first_cell,
                 int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes, bool vertices, nrf_stream_t stream_,
-                bool h2 = false) {
+                int kind = 0 /* teacher kernel: 0 fp32 MFMA, 1 fp16x2, 2 bf16x3 */) {
     if (n_cells < 0 || first_cell < 0) return NRF_ERR_SHAPE;
     if (n_cells == 0) return NRF_OK;
     if (!packed || !aabb_host || !res_host || !occ || !workspace) return NRF_ERR_NULL;
@@ -95,8 +95,9 @@ static int bake(const float* packed, const float* aabb_host, const int* res_host
     if (vertices) occ_vertex_points_kernel<<<pgrid, 256, 0, stream>>>(g, first_cell, n_cells, pts);
     else occ_points_kernel<<<pgrid, 256, 0, stream>>>(g, first_cell, n_cells, pts);
     if (int st = nrf_launch_status()) return st;
-    if (int st = h2 ? nrf_mlp_forward_points_fp16x2(packed, pts, dirs, np, raw, stream_)
-                    : nrf_mlp_forward_points(packed, pts, dirs, np, raw, stream_))
+    if (int st = kind == 1   ? nrf_mlp_forward_points_fp16x2(packed, pts, dirs, np, raw, stream_)
+                 : kind == 2 ? nrf_mlp_forward_points_bf16x3(packed, pts, dirs, np, raw, stream_)
+                             : nrf_mlp_forward_points(packed, pts, dirs, np, raw, stream_))
         return st;
     nrf_launch_begin();
     if (vertices)
@@ -120,7 +121,16 @@ NRF_EXPORT int nrf_occ_bake_fp16x2(const void* packed_teacher_h2, const float* a
                                    int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
                                    nrf_stream_t stream) {
     return bake(static_cast<const float*>(packed_teacher_h2), aabb_host, res_host, threshold, first_cell, n_cells, occ, workspace,
-                workspace_bytes, false, stream, true);
+                workspace_bytes, false, stream, 1);
+}
+
+// nrf_occ_bake with the teacher evaluated by nrf_mlp_forward_points_bf16x3 (packed_teacher_x3: nrf_pack_weights_bf16x3):
+// the fp32 kernel's 24-bit operands and range on the bf16 matrix cores
+NRF_EXPORT int nrf_occ_bake_bf16x3(const void* packed_teacher_x3, const float* aabb_host, const int* res_host, float threshold,
+                                   int64_t first_cell, int64_t n_cells, uint8_t* occ, void* workspace, int64_t workspace_bytes,
+                                   nrf_stream_t stream) {
+    return bake(static_cast<const float*>(packed_teacher_x3), aabb_host, res_host, threshold, first_cell, n_cells, occ, workspace,
+                workspace_bytes, false, stream, 2);
 }
 
 NRF_EXPORT int64_t nrf_occ_bake_vertices_workspace_bytes(int64_t n_cells) { return bake_workspace_bytes(n_cells, 1); }

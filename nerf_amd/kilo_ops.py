@@ -408,7 +408,8 @@ def kilo_composite(raw, t_start, t_end, offsets, counts, ert_eps: float, white_b
 def occ_bake(packed_teacher: torch.Tensor, aabb, res, threshold: float, chunk_cells: int = 1 << 20,
              vertices: bool = False, kind: str = "fp32") -> torch.Tensor:
     """Occupancy grid (rx,ry,rz) bool from a packed 8x256 MLP, baked `chunk_cells` cells per launch group.
-    ``kind`` "fp16x2": ``packed_teacher`` from ops.pack_weights_fp16x2, the teacher on the fp16x2 kernel (27-point rule only).
+    ``kind`` "fp16x2" / "bf16x3": ``packed_teacher`` from ops.pack_weights_fp16x2 / _bf16x3, the teacher on that kernel
+    (27-point rule only; "bf16x3" carries the fp32 kernel's 24-bit operands at about twice its rate).
     Default: KiloNeRF's `_evaluate_grid` (volumn_renderer.py:142-232: 27 sub-points per cell, teacher fine model,
     1080 B of workspace per cell).  ``vertices``: the NeRF renderer's `_build_occ_grid`
     (nerf/renderer/volume_renderer.py:156-197: one linspace vertex per voxel, 40 B per cell)."""
@@ -418,10 +419,11 @@ def occ_bake(packed_teacher: torch.Tensor, aabb, res, threshold: float, chunk_ce
     occ = torch.zeros(n, dtype=torch.uint8, device=dev)
     chunk = min(chunk_cells, n)
     L = lib()
-    if kind not in ("fp32", "fp16x2") or (kind == "fp16x2" and vertices):
+    if kind not in ("fp32", "fp16x2", "bf16x3") or (kind != "fp32" and vertices):
         raise NrfError(f"occ_bake: kind {kind!r}" + (" with vertices" if vertices else ""))
     size_fn, bake_fn = ((L.nrf_occ_bake_vertices_workspace_bytes, L.nrf_occ_bake_vertices) if vertices else
-                        (L.nrf_occ_bake_workspace_bytes, L.nrf_occ_bake if kind == "fp32" else L.nrf_occ_bake_fp16x2))
+                        (L.nrf_occ_bake_workspace_bytes, {"fp32": L.nrf_occ_bake, "fp16x2": L.nrf_occ_bake_fp16x2,
+                                                          "bf16x3": L.nrf_occ_bake_bf16x3}[kind]))
     ws = torch.empty(max(int(size_fn(chunk)), 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         for first in range(0, n, chunk):

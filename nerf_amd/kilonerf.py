@@ -319,11 +319,12 @@ class KiloRenderer(nn.Module):
     @torch.no_grad()
     def bake_occ_grid(self, teacher, occ_threshold: float = 10.0, chunk_cells: int = 1 << 20, mlp_dtype: str = "fp32"):
         """`_evaluate_grid` (volumn_renderer.py:142-232): `teacher` is the NeRF `Network` (its fine model is queried).
-        ``mlp_dtype`` "fp16x2": the teacher on the fp16x2 kernel (3.7x the rate; fp32-class densities)."""
+        ``mlp_dtype`` "bf16x3": the teacher on the three-term bf16 kernel (every operand exactly, about twice the rate);
+        "fp16x2": on the fp16x2 kernel (3.7x the rate; fp32-class densities, operands in fp16's range)."""
         from . import ops
         ws, bs = teacher.model_fine.layer_params() if hasattr(teacher.model_fine, "layer_params") else _ref_layer_params(
             teacher.model_fine)
-        packed = ops.pack_weights(ws, bs) if mlp_dtype == "fp32" else ops.pack_weights_fp16x2(ws, bs)
+        packed = {"fp32": ops.pack_weights, "bf16x3": ops.pack_weights_bf16x3, "fp16x2": ops.pack_weights_fp16x2}[mlp_dtype](ws, bs)
         aabb, _ = self.view.grid()
         self.set_occ_grid(kilo_ops.occ_bake(packed, aabb, self.occ_grid_resolution, occ_threshold, chunk_cells,
                                             kind=mlp_dtype))

@@ -347,16 +347,16 @@ def test_kilo_renderer_vs_oracle(dev, mlp_dtype):
     assert abs(float(net.get_color_reg_loss().detach()) - K.color_reg_loss(sd)) < 1e-3 * K.color_reg_loss(sd)
 
 
-@pytest.mark.parametrize("kind", ["fp32", "fp16x2"])
+@pytest.mark.parametrize("kind", ["fp32", "fp16x2", "bf16x3"])
 def test_occupancy_bake_vs_oracle(dev, kind):
-    """nrf_occ_bake / nrf_occ_bake_fp16x2 (27 sub-points per cell through the teacher's fine MLP, any sigma > threshold) against the
+    """nrf_occ_bake / nrf_occ_bake_fp16x2 / nrf_occ_bake_bf16x3 (27 sub-points per cell through the teacher's fine MLP, any sigma > threshold) against the
     oracle's restatement of _evaluate_grid on a 12x10x14 grid; cells whose deciding sigma sits within 2e-4 of the
     threshold may legitimately differ (fp32 MLP rounding) and are excluded."""
     from nerf_amd import kilo_ops, ops
     from nerf_amd.weights import make_state_dict, make_state_dict_arrays
     from oracle import kilo_oracle as K
     res, thr = [12, 10, 14], 2.25      # random-init teacher: max sigma per cell spans 1.7 .. 2.8
-    pack = ops.pack_state_dict if kind == "fp32" else ops.pack_state_dict_fp16x2
+    pack = {"fp32": ops.pack_state_dict, "fp16x2": ops.pack_state_dict_fp16x2, "bf16x3": ops.pack_state_dict_bf16x3}[kind]
     packed = pack(make_state_dict_arrays(0, 30.0, 2.0), "model_fine", dev)
     occ = kilo_ops.occ_bake(packed, AABB, res, thr, chunk_cells=500, kind=kind).cpu().numpy()      # 4 chunks, ragged tail
     ref, sig = K.bake(make_state_dict(0, 30.0, 2.0), AABB[:3], AABB[3:], res, thr, want_sigma=True)

@@ -13,8 +13,8 @@ from nerf_amd.weights import make_state_dict_arrays  # noqa: E402
 dev = torch.device("cuda:0")
 res = [int(sys.argv[1])] * 3 if len(sys.argv) > 1 else [256] * 3
 grids = {}
-for kind in ("fp32", "fp16x2"):
-    pack = ops.pack_state_dict if kind == "fp32" else ops.pack_state_dict_fp16x2
+for kind in ("fp32", "bf16x3", "fp16x2"):
+    pack = {"fp32": ops.pack_state_dict, "bf16x3": ops.pack_state_dict_bf16x3, "fp16x2": ops.pack_state_dict_fp16x2}[kind]
     packed = pack(make_state_dict_arrays(0, 30.0, 2.0), "model_fine", dev)
     kilo_ops.occ_bake(packed, [-1, -1, -1, 1, 1, 1], [32, 32, 32], 2.25, kind=kind)
     torch.cuda.synchronize()
@@ -24,4 +24,5 @@ for kind in ("fp32", "fp16x2"):
     dt = time.perf_counter() - t0
     n = res[0] * res[1] * res[2] * 27
     print(f"bake {res} ({kind} teacher): {dt:.3f} s, {n / dt / 1e6:.1f} M evals/s, {n * 1186816 / dt / 1e12:.1f} TFLOP/s, occupied {float(occ.float().mean()):.3f}")
-print(f"cells that differ between the two grids: {int((grids['fp32'] != grids['fp16x2']).sum())} of {grids['fp32'].numel()}")
+for kind in ("bf16x3", "fp16x2"):
+    print(f"cells that differ between the fp32 and the {kind} grid: {int((grids['fp32'] != grids[kind]).sum())} of {grids['fp32'].numel()}")
