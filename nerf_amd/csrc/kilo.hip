@@ -22,7 +22,6 @@
 #include "kilo_common.h"
 #include "split2h.h"
 #include "split3.h"
-#include "m16.h"
 
 namespace {
 
@@ -252,16 +251,10 @@ __global__ __launch_bounds__(256) void kilo_dir_table_kernel(const float* __rest
         ovf = fmaxf(ovf, __shfl_xor(ovf, 32));
         if (row < n_dirs && h == 0) guard[row] = ovf;
     } else if constexpr (KIND == 2) {
-        // the bf16x3 kernel runs on v_mfma_*_16x16x32 (m16.h): a row is [lane group g][term] fragments of 8 slots each;
-        // group 2 y + h holds registers 4 y .. + 3 and 8 + 4 y .. + 3 of lane half h, i.e. dwords 2 y, 2 y + 1 of both of this
-        // half's 32x32-form fragments -- the operand split is per register pair, so the bits are those of a tile that
-        // encodes for itself (to_m16, then the split)
         u32x4 f[2][3];
         split_block_x3(SplitSel::make(), e[0], f);
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) out[y * 3 + t] = u32x4{f[0][t][2 * y], f[0][t][2 * y + 1], f[1][t][2 * y], f[1][t][2 * y + 1]};
+        for (int q = 0; q < 6; ++q) out[q] = f[q / 3][q % 3];
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -269,15 +262,9 @@ __global__ __launch_bounds__(256) void kilo_dir_table_kernel(const float* __rest
             for (int c = 0; c < 4; ++c) out[q][c] = __float_as_uint(e[0][4 * q + c]);
     }
     if (row < n_dirs) {
-        if constexpr (KIND == 2) {   // groups h and 2 + h of the row's [g][term]
-            u32x4* dst = reinterpret_cast<u32x4*>(table + row * 48);
+        u32x4* dst = reinterpret_cast<u32x4*>(table + (row * 2 + h) * (NQ * 4));
 #pragma unroll
-            for (int q = 0; q < 6; ++q) dst[((q / 3) * 2 + h) * 3 + q % 3] = out[q];
-        } else {
-            u32x4* dst = reinterpret_cast<u32x4*>(table + (row * 2 + h) * (NQ * 4));
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) dst[q] = out[q];
-        }
+        for (int q = 0; q < NQ; ++q) dst[q] = out[q];
     }
 }
 
@@ -654,15 +641,9 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_h2_kernel(const float* __rest
 // Record: 12 k16-steps of (hi | mid | lo) fragments = 36 KiB + the fp32 kernel's small block.  hi and mid stay in registers
 // for the job (96, as the other two kernels); the lo fragments -- one of a step's six MFMAs reads them -- sit in a
 // wave-private LDS slice (12 KiB per wave, each lane re-reads only what it wrote: no barrier) so that two waves per SIMD fit.
-// Round 3: on v_mfma_f32_16x16x32_bf16 (m16.h): a step is 16 rows x 32 k, steps [k-block][row half]; a 32 x 32 output block
-// is four 16 x 16 accumulators, so a k-block's 24 MFMAs run as four independent chains (the 32x32x16 form's six per step all
-// waited for each other), and the chip holds a higher clock on this shape.
 constexpr int kKX3Steps = 12;
 constexpr int kKiloX3MatFloats = kKX3Steps * 3 * 256;                 // 9216
-// the record's small block in the 16x16x32 form: biases [4 layers][g][16], sigma weights [g][8], rgb weights [c][g][8]
-constexpr int kK16Bias = 0, kK16SigW = 256, kK16RgbW = 288, kK16SigB = 384, kK16RgbB = 385, kK16Small = 416;
-constexpr int kKiloCellFloatsX3 = kKiloX3MatFloats + kK16Small;       // 9632
-static_assert(kK16Small % 4 == 0 && kK16Small / 4 - 64 <= 64 && kKiloCellFloatsX3 % 4 == 0, "float4 staging of the small block");
+constexpr int kKiloCellFloatsX3 = kKiloX3MatFloats + kKiloSmall;      // 9504
 
 
 __global__ __launch_bounds__(256) void kilo_pack_x3_kernel(KiloSrc s, int num_cells, float* __restrict__ packed) {
@@ -673,22 +654,19 @@ __global__ __launch_bounds__(256) void kilo_pack_x3_kernel(KiloSrc s, int num_ce
     unsigned short* frag = reinterpret_cast<unsigned short*>(packed + int64_t(cell) * kKiloCellFloatsX3);
     for (int idx = threadIdx.x; idx < kKX3Steps * 512; idx += 256) {   // same (step, lane, element) -> weight map as kilo_pack_h2_kernel
         const int jj = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
-        // A fragment of the 16x16x32 form: rows 16 (step & 1) + (lane & 15); element jj of lane group g is slot phi of the
-        // k-block = register t of lane half h in the 32x32 form the encodings are made in (split_stream.h: xpack_fetch)
-        const int phi = m16_slot(lane >> 4, jj), t = 4 * (phi >> 3) + (phi & 3), h = (phi >> 2) & 1;
-        const int row = 16 * (step & 1) + (lane & 15);
+        const int h = lane >> 5, row = lane & 31;
         float v = 0.f;
         if (step < 4) {
-            const int c = pe_col((step >> 1) * 16 + t, h, 10);
+            const int c = pe_col((step >> 1) * 16 + 8 * (step & 1) + jj, h, 10);
             if (c >= 0) v = rec[REC_OFF(0) + row * 63 + c];
         } else if (step < 6) {
-            v = rec[REC_OFF(2) + row * 32 + phi];
+            v = rec[REC_OFF(2) + row * 32 + acc_row(8 * (step & 1) + jj, h)];
         } else if (step < 8) {
-            v = rec[REC_OFF(4) + row * 32 + phi];
+            v = rec[REC_OFF(4) + row * 32 + acc_row(8 * (step & 1) + jj, h)];
         } else if (step < 10) {
-            v = rec[REC_OFF(8) + row * 59 + phi];
+            v = rec[REC_OFF(8) + row * 59 + acc_row(8 * (step & 1) + jj, h)];
         } else {
-            const int c = pe_col(t, h, 4);
+            const int c = pe_col(8 * (step & 1) + jj, h, 4);
             if (c >= 0) v = rec[REC_OFF(8) + row * 59 + 32 + c];
         }
         const __bf16 b0 = (__bf16)v;
@@ -699,22 +677,22 @@ __global__ __launch_bounds__(256) void kilo_pack_x3_kernel(KiloSrc s, int num_ce
         frag[step * 1536 + 512 + lane * 8 + jj] = __builtin_bit_cast(unsigned short, b1);
         frag[step * 1536 + 1024 + lane * 8 + jj] = __builtin_bit_cast(unsigned short, b2);
     }
-    for (int i = threadIdx.x; i < kK16Small; i += 256) {
+    for (int i = threadIdx.x; i < kKiloSmall; i += 256) {   // the fp32 kernel's small block (kilo_pack_kernel)
         float v = 0.f;
-        if (i < kK16SigW) {
-            const int layer = i >> 6, g = (i >> 4) & 3, r = i & 15;
+        if (i < 128) {
+            const int layer = i >> 5, h = (i >> 4) & 1, r = i & 15;
             const int off = layer == 0 ? REC_OFF(1) : layer == 1 ? REC_OFF(3) : layer == 2 ? REC_OFF(5) : REC_OFF(9);
-            v = rec[off + m16_slot(g, r & 7)];
-        } else if (i < kK16RgbW) {
-            const int j = i - kK16SigW;
-            v = rec[REC_OFF(6) + m16_slot(j >> 3, j & 7)];
-        } else if (i < kK16SigB) {
-            const int j = i - kK16RgbW;
-            v = rec[REC_OFF(10) + (j >> 5) * 32 + m16_slot((j >> 3) & 3, j & 7)];
-        } else if (i == kK16SigB) {
+            v = rec[off + acc_row(r, h)];
+        } else if (i < 160) {
+            const int h = ((i - 128) >> 4) & 1, r = i & 15;
+            v = rec[REC_OFF(6) + acc_row(r, h)];
+        } else if (i < 256) {
+            const int j = i - 160, c = j >> 5, h = (j >> 4) & 1, r = j & 15;
+            v = rec[REC_OFF(10) + c * 32 + acc_row(r, h)];
+        } else if (i == kKOffSigB) {
             v = rec[REC_OFF(7)];
-        } else if (i < kK16RgbB + 3) {
-            v = rec[REC_OFF(11) + (i - kK16RgbB)];
+        } else if (i < kKOffRgbB + 3) {
+            v = rec[REC_OFF(11) + (i - kKOffRgbB)];
         }
         packed[int64_t(cell) * kKiloCellFloatsX3 + kKiloX3MatFloats + i] = v;
     }
@@ -735,48 +713,38 @@ __device__ unsigned long long g_kf_stamps[16];
 #define KF_T(i, pin) do {} while (0)
 #endif
 
-// One 32-row output block of a tiny layer on the bf16 pipe as four 16 x 16 accumulators (row half mh x point half nb): per
-// k-block the six products (small terms first, mlp_bf16x3.hip's order) of each, interleaved -- four independent chains.
-// `w`: steps [k-block][row half], hi and mid fragments; `wlo`: this lane's lo fragments in LDS, 64 u32x4 per step;
-// `x`: [k-block][point half][term].  The result is the block in m16.h's register order (8 nb + 4 mh + r).
-#define NRF_MFMA_K16(a, b, c) \
-    __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+// One 32x32 output block of a tiny layer on the bf16 pipe, six MFMAs per k16-step into one accumulator, small terms first
+// (mlp_bf16x3.hip's order); `wlo`: this lane's lo fragments in LDS, 64 u32x4 per step.
 template <int NKB>
 __device__ __forceinline__ f32x16 tiny_layer_x3(const u32x4 (*w)[2], const u32x4* wlo, f32x16 init, const u32x4 (*x)[2][3]) {
-    f32x4 q[2][2];   // [mh][nb]
-    blk16_get<0>(init, q[0][0], q[0][1]);
-    blk16_get<1>(init, q[1][0], q[1][1]);
+    f32x16 y = init;
+#ifdef KILO_ABL_NOMFMA   // timing-only ablation: the layer without its MFMAs (operands still consumed)
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        const u32x4 lo[2] = {wlo[(kb * 2) * 64], wlo[(kb * 2 + 1) * 64]};
-#define KILO_X3_TERM(WSEL, T)                                                   \
-    _Pragma("unroll") for (int mh = 0; mh < 2; ++mh)                            \
-        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                        \
-            q[mh][nb] = NRF_MFMA_K16(WSEL, x[kb][nb][T], q[mh][nb]);
-        KILO_X3_TERM(lo[mh], 0)
-        KILO_X3_TERM(w[kb * 2 + mh][0], 2)
-        KILO_X3_TERM(w[kb * 2 + mh][1], 1)
-        KILO_X3_TERM(w[kb * 2 + mh][1], 0)
-        KILO_X3_TERM(w[kb * 2 + mh][0], 1)
-        KILO_X3_TERM(w[kb * 2 + mh][0], 0)
-#undef KILO_X3_TERM
-    }
-    f32x16 y;
-    blk16_put<0>(y, q[0][0], q[0][1]);
-    blk16_put<1>(y, q[1][0], q[1][1]);
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int st = kb * 2 + s2;
+            const u32x4 w2 = wlo[st * 64];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                y[c] += __uint_as_float(w2[c] ^ w[st][0][c] ^ w[st][1][c] ^ x[kb][s2][0][c] ^ x[kb][s2][1][c] ^ x[kb][s2][2][c]);
+        }
     return y;
-}
-// heads in the 16x16x32 form: registers 0..7 of a block are point c's, 8..15 point 16 + c's; `w`: this group's 8 weights
-__device__ __forceinline__ void dot8x2(const float* w, const f32x16& x, float& s0, float& s1) {
-    const f32x4 wl = *reinterpret_cast<const f32x4*>(w), wh = *reinterpret_cast<const f32x4*>(w + 4);
-    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#endif
 #pragma unroll
-    for (int t = 0; t < 8; t += 2) {
-        const f32x2 ww = t < 4 ? (f32x2){wl[t], wl[t + 1]} : (f32x2){wh[t - 4], wh[t - 3]};
-        a0 = __builtin_elementwise_fma(ww, (f32x2){x[t], x[t + 1]}, a0);
-        a1 = __builtin_elementwise_fma(ww, (f32x2){x[8 + t], x[9 + t]}, a1);
-    }
-    s0 = a0[0] + a0[1], s1 = a1[0] + a1[1];
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int st = kb * 2 + s2;
+            const u32x4 w2 = wlo[st * 64];
+            y = NRF_MFMA_X3(w2, x[kb][s2][0], y);
+            y = NRF_MFMA_X3(w[st][0], x[kb][s2][2], y);
+            y = NRF_MFMA_X3(w[st][1], x[kb][s2][1], y);
+            y = NRF_MFMA_X3(w[st][1], x[kb][s2][0], y);
+            y = NRF_MFMA_X3(w[st][0], x[kb][s2][1], y);
+            y = NRF_MFMA_X3(w[st][0], x[kb][s2][0], y);
+        }
+    return y;
 }
 
 template <bool INDEXED, bool TABLE>   // TABLE: `dirs` is the table of kilo_dir_table_kernel<2>
@@ -786,11 +754,11 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
                                                              const int* __restrict__ perm, const float* __restrict__ pts,
                                                              const float* __restrict__ dirs,
                                                              const int* __restrict__ dir_index, float4* __restrict__ raw, int* __restrict__ job_counter) {
-    __shared__ __attribute__((aligned(16))) float s_small[4][kK16Small];
+    __shared__ __attribute__((aligned(16))) float s_small[4][kKiloSmall];
     __shared__ u32x4 s_wlo[4][kKX3Steps][64];
     const SplitSel sel = SplitSel::make();
     const int lane = threadIdx.x & 63;
-    const int j = lane & 31, h = lane >> 5, g = lane >> 4;   // gathers and encodings per point j (32x32 form); blocks per group g
+    const int j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the job's search and pointers become scalar
     const int total_jobs = job_prefix[ncell];
 #ifdef KF_STAMP
@@ -818,17 +786,17 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
         float* sm_job = s_small[wave];   // wave-private: no barrier (kilo_mlp_kernel)
         {
             const float4* src = reinterpret_cast<const float4*>(cw + kKiloX3MatFloats);
-            const float4 s0 = src[lane], s1 = src[lane < kK16Small / 4 - 64 ? 64 + lane : lane];
+            const float4 s0 = src[lane], s1 = src[lane < kKiloSmall / 4 - 64 ? 64 + lane : lane];
             // every load of this job's record is issued: the next job (its ticket was drawn a job ago) gets its cell now
             job_n = drawn ? __builtin_amdgcn_readfirstlane(ticket) : job + n_waves;
             if (drawn) ticket = job_ticket(job_counter, lane);
             cell_n = job_n < total_jobs ? job_cell_of(job_prefix, ncell, job_n) : 0;
             reinterpret_cast<float4*>(sm_job)[lane] = s0;
-            if (lane < kK16Small / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = s1;
+            if (lane < kKiloSmall / 4 - 64) reinterpret_cast<float4*>(sm_job)[64 + lane] = s1;
         }
-        const float* bias_job = sm_job + kK16Bias + g * 16;
-        const float sb = cw[kKiloX3MatFloats + kK16SigB], rb0 = cw[kKiloX3MatFloats + kK16RgbB],
-                    rb1 = cw[kKiloX3MatFloats + kK16RgbB + 1], rb2 = cw[kKiloX3MatFloats + kK16RgbB + 2];
+        const float* bias_job = sm_job + kKOffBias + h * 16;
+        const float sb = cw[kKiloX3MatFloats + kKOffSigB], rb0 = cw[kKiloX3MatFloats + kKOffRgbB],
+                    rb1 = cw[kKiloX3MatFloats + kKOffRgbB + 1], rb2 = cw[kKiloX3MatFloats + kKOffRgbB + 2];
         auto lds16 = [](const float* p) { return *reinterpret_cast<const f32x16*>(p); };
 
         const int last = seg_e - 1;   // gather pipeline: kilo_mlp_kernel
@@ -858,17 +826,17 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
             const float px = pc[0], py = pc[1], pz = pc[2], dx = dc[0], dy = dc[1], dz = dc[2];
             f32x16 e[2];
             u32x4 xpe[2][2][3], xh[1][2][3], xv[2][2][3];
-            if (TABLE) {   // this tile's direction fragments: of the rows of its two points' rays (point c and point 16 + c;
-                           // the lane gathered for point j = 16 (g & 1) + c, the other one's row index comes from the
-                           // neighbouring group), this lane group's 48 B each
-                const unsigned di_o = __shfl_xor(di_c, 16);
-                const unsigned di2[2] = {(g & 1) ? di_o : di_c, (g & 1) ? di_c : di_o};
+            if (TABLE) {   // this tile's direction fragments: the table row of its ray, this lane half's 96 B
+                const u32x4* row = reinterpret_cast<const u32x4*>(dirs) + (size_t(di_c) * 2u + unsigned(h)) * 6u;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const u32x4* row = reinterpret_cast<const u32x4*>(dirs) + (size_t(di2[nb]) * 4u + unsigned(g)) * 3u;
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) xv[1][nb][t] = row[t];
-                }
+                    for (int t = 0; t < 3; ++t)
+#ifdef KILO_ABL_NOTABLE   // timing-only ablation: no direction rows
+                        xv[1][s2][t] = u32x4{di_c, di_c + t, di_c, unsigned(size_t(row))};
+#else
+                        xv[1][s2][t] = row[s2 * 3 + t];
+#endif
             }
             {
                 float dn[3] = {0.f, 0.f, 0.f}, pnn[3];
@@ -885,8 +853,8 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
             }
             encode_pe_doubling<10>(px, py, pz, h, e);
             KF_T(2, e[1]);   // (waits for this tile's point) position encoding
-            split_block_x3(sel, to_m16(e[0]), xpe[0]);   // made in the 32x32 form, handed over (m16.h)
-            split_block_x3(sel, to_m16(e[1]), xpe[1]);
+            split_block_x3(sel, e[0], xpe[0]);
+            split_block_x3(sel, e[1], xpe[1]);
             KF_T(3, xpe[1][1][2]);   // its split
             int again = 0;   // keeps the LDS reads below inside the tile loop (kilo_mlp_kernel)
             asm volatile("" : "+v"(again));
@@ -897,30 +865,26 @@ __global__ __launch_bounds__(256, 2) void kilo_mlp_x3_kernel(const float* __rest
             KF_T(4, y);
             split_block_x3(sel, y, xh[0]);
             KF_T(5, xh[0][1][2]);
-            y = relu16(tiny_layer_x3<1>(w + 4, wlo + 4 * 64, lds16(bias_h + 64), xh));            // pts_linears 1
+            y = relu16(tiny_layer_x3<1>(w + 4, wlo + 4 * 64, lds16(bias_h + 32), xh));            // pts_linears 1
             KF_T(6, y);
-            float sg[2], cr[2], cg[2], cb[2];   // head sums of the lane's two points
-            dot8x2(sm + kK16SigW + g * 8, y, sg[0], sg[1]);                                         // sigma_linear (:142-144)
+            float sigma = dot16(lds16(sm + kKOffSigW + h * 16), y);                                 // sigma_linear (:142-144)
             split_block_x3(sel, y, xh[0]);
             KF_T(7, xh[0][1][2]);
-            y = tiny_layer_x3<1>(w + 6, wlo + 6 * 64, lds16(bias_h + 128), xh);                    // feature_linear (:147-149), no activation
+            y = tiny_layer_x3<1>(w + 6, wlo + 6 * 64, lds16(bias_h + 64), xh);                     // feature_linear (:147-149), no activation
             KF_T(8, y);
             split_block_x3(sel, y, xv[0]);
             KF_T(9, xv[0][1][2]);
             if (!TABLE) {
                 encode_pe_doubling<4>(dx, dy, dz, h, e);
-                split_block_x3(sel, to_m16(e[0]), xv[1]);
+                split_block_x3(sel, e[0], xv[1]);
             }
-            f32x16 hv = relu16(tiny_layer_x3<2>(w + 8, wlo + 8 * 64, lds16(bias_h + 192), xv));  // view_linears on cat([feature, dirs]) (:152-156)
+            f32x16 hv = relu16(tiny_layer_x3<2>(w + 8, wlo + 8 * 64, lds16(bias_h + 96), xv));   // view_linears on cat([feature, dirs]) (:152-156)
             KF_T(10, hv);  // (waits for the tile's direction rows)
             // rgb_linear (:159-161)
-            dot8x2(sm + kK16RgbW + g * 8, hv, cr[0], cr[1]);
-            dot8x2(sm + kK16RgbW + 32 + g * 8, hv, cg[0], cg[1]);
-            dot8x2(sm + kK16RgbW + 64 + g * 8, hv, cb[0], cb[1]);
-            const bool odd = (g & 1) != 0;   // lane l < 32 ends with point l's sums (m16.h: add_groups)
-            const float r = add_groups(cr[0], cr[1], odd), gr = add_groups(cg[0], cg[1], odd), b = add_groups(cb[0], cb[1], odd);
-            const float sigma = add_groups(sg[0], sg[1], odd);
-            if (lane < 32 && valid) raw[id] = make_float4(r + rb0, gr + rb1, b + rb2, sigma + sb);
+            float r = dot16(lds16(sm + kKOffRgbW + h * 16), hv), g = dot16(lds16(sm + kKOffRgbW + 32 + h * 16), hv),
+                  b = dot16(lds16(sm + kKOffRgbW + 64 + h * 16), hv);
+            r = nrf_add_halves(r), g = nrf_add_halves(g), b = nrf_add_halves(b), sigma = nrf_add_halves(sigma);
+            if (h == 0 && valid) raw[id] = make_float4(r + rb0, g + rb1, b + rb2, sigma + sb);
             KF_T(11, kf_none);  // heads and store
         }
     }

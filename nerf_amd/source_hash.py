@@ -18,7 +18,7 @@ SOURCES = {
     "bf16x3": ("mlp_bf16x3.hip", "split3.h", "split_stream.h", "m16.h"),
     "fp16x2": ("mlp_fp16x2.hip", "split2h.h", "split_stream.h"),
     "composite": ("composite.hip",),
-    "kilo": ("kilo.hip", "kilo_common.h", "split2h.h", "split3.h", "m16.h"),
+    "kilo": ("kilo.hip", "kilo_common.h", "split2h.h", "split3.h"),
 }
 
 
