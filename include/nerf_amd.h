@@ -118,10 +118,11 @@ int nrf_mlp_forward_points_bf16(const void* packed_bf16, const float* pts, const
 
 /* Same network and reference path again (network.py:49-74, 171-195, volume_renderer.py:227-231, 393-423).  Every fp32
  * weight and every layer input is split into three bf16 terms (a = a0 + a1 + a2, 24 significand bits) and each product
- * is the six v_mfma_f32_32x32x16_bf16 with i + j <= 2, fp32 accumulation; the dropped terms are 2^-24 of the product
- * (fp32's own rounding unit).  fp32 biases and fp32 alpha / rgb heads.  Results are fp32-class (as close to a float64
- * evaluation as the fp32 reference is: tests/test_gpu_bf16x3.py), at 6 / 16 of the fp32 MFMA time on paper.
- * n_samples must be a multiple of 32. */
+ * is the six bf16 MFMAs with i + j <= 2 (v_mfma_f32_16x16x32_bf16 in the forward kernels), fp32 accumulation;
+ * the dropped terms are 2^-24 of the product (fp32's own rounding unit).  fp32 biases and fp32 alpha / rgb heads.  Results
+ * are fp32-class (as close to a float64 evaluation as the fp32 reference is: tests/test_gpu_bf16x3.py), at 6 / 16 of the
+ * fp32 MFMA time on paper.  n_samples must be a multiple of 32.  The packed stream is private to the library (its layout
+ * follows the kernels' MFMA shape): size it with nrf_packed_bf16x3_bytes(), fill it with nrf_pack_weights_bf16x3. */
 int64_t nrf_packed_bf16x3_bytes(void);
 int nrf_pack_weights_bf16x3(const float* const* w, const float* const* b, void* packed_x3, nrf_stream_t stream);
 int nrf_mlp_forward_rays_bf16x3(const void* packed_x3, const float* rays_o, const float* rays_d, const float* z,
