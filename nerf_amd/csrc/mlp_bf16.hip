@@ -121,9 +121,12 @@ __global__ void bpack_layer_kernel(BPackLayer p) {
 
 // ---- LDS ring of the bf16 stream --------------------------------------------------------------
 struct BRing {
-    const char* gnext;   // per lane: this lane's 16 B of piece PW*w of the next chunk to prefetch
-    const char* gbegin;
-    const char* gend;
+    // the stream is addressed as a UNIFORM base that walks the chunks (scalar registers) + one 32-bit lane offset
+    // (global_load_lds_dwordx4 voff, s[base]; mlp_bf16x3.hip: XRingS): no per-lane 64-bit pointers, no vector address arithmetic
+    const char* snext;   // this wave's piece 0 of the next chunk to prefetch
+    const char* sbegin;
+    const char* send;
+    unsigned voff;       // lane * 16
     unsigned lds_base;   // LDS byte address of smem + wave * PW KiB (this wave fills pieces PW*w .. PW*w+PW-1)
     char* smem;
     int pf_slot, rd_slot;
@@ -141,12 +144,19 @@ __device__ __forceinline__ void br_prefetch_piece(const BRing& st, int j) {
 #endif
     // readfirstlane: the slot index is uniform, but under SGPR pressure the compiler may keep it in a VGPR, and the
     // asm's M0 operand must be a scalar register (folds away when it already is one)
-    glds16(st.gnext + j * 1024, __builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kBChunkBytes + j * 1024));
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(st.voff), "s"(st.snext + j * 1024),
+          "s"(__builtin_amdgcn_readfirstlane(st.lds_base + unsigned(st.pf_slot) * kBChunkBytes + j * 1024))
+        : "memory");
 }
 __device__ __forceinline__ void br_prefetch_advance(BRing& st) {
-    const char* nx = st.gnext + kBChunkBytes;
-    st.gnext = nx == st.gend ? st.gbegin : nx;
-    asm volatile("" : "+v"(st.gnext));  // keep it a run-time value (see ws_prefetch_advance)
+    const char* nx = st.snext + kBChunkBytes;
+    st.snext = nx == st.send ? st.sbegin : nx;
+    asm volatile("" : "+s"(st.snext));  // keep it a run-time value (see ws_prefetch_advance)
     st.pf_slot = st.pf_slot + 1 == kBRing ? 0 : st.pf_slot + 1;
 }
 // Next chunk readable: it was issued two chunk-times ago; the two batches of PW pieces (PW = 32 / waves: this wave's
@@ -165,9 +175,10 @@ __device__ __forceinline__ void br_acquire(BRing& st, int lane) {
 // slot chunk c-1 just left.
 template <int PW>
 __device__ __forceinline__ void br_start(BRing& st, const char* stream_base, char* smem, int wave, int lane) {
-    st.gbegin = stream_base + wave * (PW * 1024) + lane * 16;
-    st.gend = st.gbegin + size_t(kBChunks) * kBChunkBytes;
-    st.gnext = st.gbegin;
+    st.sbegin = stream_base + wave * (PW * 1024);
+    st.send = st.sbegin + size_t(kBChunks) * kBChunkBytes;
+    st.snext = st.sbegin;
+    st.voff = unsigned(lane) * 16u;
     st.smem = smem;
     st.lds_base = __builtin_amdgcn_readfirstlane(unsigned(reinterpret_cast<uintptr_t>((lds_vptr)smem)) + unsigned(wave) * unsigned(PW * 1024));
     st.pf_slot = 0;
@@ -203,12 +214,13 @@ __device__ unsigned long long g_bf_stamps[256 * 8 * 128];
 #define NRF_MFMA_BF16(a, b, c) \
     __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-// Activation of a finished accumulator block: max(bits, lim) as integers is relu for lim = 0 (negative floats are
-// negative ints) and the identity for lim = INT_MIN, so "relu or not" is a run-time scalar, not another code body.
-// (relu on the PACKED pairs, one v_pk_max_i16 against 0 or 0x80008000 -- both halves of the limit word matter --
-// gives the same bits with half the instructions, and measured 2 % SLOWER on the same box, 144.9 vs 141.5 ms per
-// frame: the activation then waits for the conversion instead of running ahead of it.  Not used.)
-constexpr int kActRelu = 0, kActNone = int(0x80000000u);
+// Activation of a finished accumulator block, on the PACKED bf16 pair: v_pk_max_i16 against 0 is relu (negative bf16 are
+// negative int16) and against 0x8000 the identity, so "relu or not" is a run-time scalar, not another code body.  (On the
+// 32x32x16 kernel this form measured 2 % SLOWER than two v_max_i32 on the fp32 bits ahead of the conversion -- the
+// activation waits for the conversion -- and was not used; on the 16x16x32 kernel, where the clock follows the energy a tile
+// costs, the 768 instructions it saves per 64-point tile are -2.7 %: 130.6 -> 127.0 ms per frame, old and new alternately
+// on one box.)
+constexpr unsigned kPkRelu = 0u, kPkNone = 0x80008000u;
 
 // Block epilogues come in SLICES.  A finished 32-row block needs 3 VALU instructions per packed output register
 // (two v_max_i32 on the fp32 bits, one v_cvt_pk_bf16_f32), 48 or 96 per block; issued as one lump they stop the wave's
@@ -221,12 +233,18 @@ template <int NSETS>
 struct EpiPack {  // hidden layers: activate + pack block ob of every set into the next layer's input
     static constexpr int Q = 8 * NSETS;   // slices per block: one packed output register each
     u32x4 (*Xout)[8][2];
-    int lim;                              // kActRelu / kActNone
+    unsigned lim16;                       // kPkRelu / kPkNone: the activation's limit for a packed bf16 pair
     __device__ __forceinline__ void begin(int) {}
     __device__ __forceinline__ void slice(int ob, const f32x16 (&y)[NSETS], int q) {
         const int set = q / 8, s = (q % 8) / 4, i = q % 4;
-        const int b0 = __float_as_int(y[set][8 * s + 2 * i]), b1 = __float_as_int(y[set][8 * s + 2 * i + 1]);
-        Xout[set][ob][s][i] = pack_bf16(__int_as_float(b0 > lim ? b0 : lim), __int_as_float(b1 > lim ? b1 : lim));
+        // relu AFTER the conversion, on the packed pair: one v_pk_max_i16 against 0 (or 0x8000: no activation) per half --
+        // a negative bf16 is a negative int16, and rounding keeps the sign, so the bits are those of relu-then-convert with
+        // two v_max_i32 less per pair.  (asm: written as a vector max the compiler un-packs the conversion; its operand is
+        // a VALU result, so the MFMA hazard pass has nothing to see here.)
+        const unsigned pk = pack_bf16(y[set][8 * s + 2 * i], y[set][8 * s + 2 * i + 1]);
+        unsigned r;
+        asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(pk), "s"(lim16));
+        Xout[set][ob][s][i] = r;
     }
 };
 template <int NSETS>
@@ -411,19 +429,19 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
 #endif
         BF_STAMP_AT(0);
         u32x4 pe[NSETS][2][2], dpe[NSETS][2];
+        float pdir[NSETS][3];   // POINTS: the sets' own directions, encoded in front of the views layer (below)
         if constexpr (POINTS) {
 #pragma unroll
             for (int set = 0; set < NSETS; ++set) {
                 int64_t pt = tile * TP + 32 * set + j;
                 pt = pt < n_points ? pt : n_points - 1;   // tail lanes repeat the last point (stores are masked)
                 const float px = rays_o[pt * 3], py = rays_o[pt * 3 + 1], pz = rays_o[pt * 3 + 2];
-                const float dx = rays_d[pt * 3], dy = rays_d[pt * 3 + 1], dz = rays_d[pt * 3 + 2];
-                f32x16 enc[2], denc[1];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pdir[set][a] = rays_d[pt * 3 + a];
+                f32x16 enc[2];
                 encode_pe_doubling<10>(px, py, pz, h, enc);
-                encode_pe_doubling<4>(dx, dy, dz, h, denc);
                 pack_tile(to_m16(enc[0]), pe[set][0]);   // made in the 32x32 form, handed over (m16.h)
                 pack_tile(to_m16(enc[1]), pe[set][1]);
-                pack_tile(to_m16(denc[0]), dpe[set]);
             }
         } else {
             const int64_t ray = tile / tiles_per_ray;
@@ -453,8 +471,8 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
         BF_STAMP_AT(1);
         u32x4 XA[NSETS][8][2], XB[NSETS][8][2];
         f32x16 acc[2][NSETS];                 // accumulator blocks [ob & 1][set], shared by all layers (see bf_layer)
-        EpiPack<NSETS> toA{XA, kActRelu};     // the epilogue a layer writing XA leaves pending for its successor
-        EpiPack<NSETS> toB{XB, kActRelu};
+        EpiPack<NSETS> toA{XA, kPkRelu};      // the epilogue a layer writing XA leaves pending for its successor
+        EpiPack<NSETS> toB{XB, kPkRelu};
         bf_layer<NSETS, 8, 2, 0, 0, kBStepsL0, false>(st, lane, bias_h, pe, nullptr, nullptr, toA, acc, toA);     // pts_linears.0
         BF_STAMP_AT(2);
         // pts1..7 + feature as 4 pairs (XA -> XB -> XA); pair 2 starts with the skip layer, the last layer of pair 3
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
 #ifdef BF_STAMP
             st.stamp_base = stamp_tile ? 26 + 20 * p : -1;
 #endif
-            toA.lim = p == 3 ? kActNone : kActRelu;                                                               // feature_linear: no activation
+            toA.lim16 = p == 3 ? kPkNone : kPkRelu;                                                               // feature_linear: no activation
             bf_layer<NSETS, 8, 0, 8, 0, kBStepsHidden, true>(st, lane, b0 + 512, nullptr, XB, nullptr, toA, acc, toB);
             BF_STAMP_AT(4 + 2 * p);
 #ifdef BF_STAMP
@@ -503,6 +521,17 @@ __global__ __launch_bounds__(2048 / (4 * NSETS), 1) void mlp_bf16_kernel(const c
             asm volatile("" : "+v"(sigma[set][0]), "+v"(sigma[set][1]));   // pinned here: sunk behind the views layer it would keep the block alive across it
         }
         BF_STAMP_AT(11);
+        if constexpr (POINTS) {
+            // every set has its own direction fragments here: carried through the eight hidden layers they are 8 registers
+            // more than the kernel has (scratch reloads in the layer loop, each draining the LDS-DMA ring); three floats
+            // per set are carried instead and encoded now
+#pragma unroll
+            for (int set = 0; set < NSETS; ++set) {
+                f32x16 denc[1];
+                encode_pe_doubling<4>(pdir[set][0], pdir[set][1], pdir[set][2], h, denc);
+                pack_tile(to_m16(denc[0]), dpe[set]);
+            }
+        }
         // views_linears.0 on cat([feature (XA, no activation), dir PE]) -> 128, relu, rgb_linear
         EpiRgb<NSETS> er;
         er.rw = cst + kS16RgbW + g * 8;
