@@ -527,9 +527,9 @@ __device__ __forceinline__ void x16_pe_layer(XRingS& st, int lane, const float* 
     auto none = [](int) {};
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob) {
-        const Blk16 bias = bias16(bias_g, ob);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) Y[ob].v[t] = accum ? Y[ob].v[t] : bias.v[t];
+        // (a uniform branch around the block's four LDS reads, not sixteen selects: the flag is a scalar, and the 256 selects
+        // per tile were instructions that nothing hid)
+        if (!accum) Y[ob] = bias16(bias_g, ob);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
