@@ -7,6 +7,12 @@
 // v_mfma_f32_32x32x2_f32 (512 cycles): 2.67x the fp32 MFMA rate on paper.  Same reference path as mlp_fp32.hip
 // (volume_renderer.py:227-231, 393-423, network.py:49-74, 171-195, encoding/freq.py:31-32).
 //
+// Two forms of the same chain live here: the forward kernels (inference and training forward) issue
+// v_mfma_f32_16x16x32_bf16 -- mlp_bf16x3_m16_kernel, further down: the chip holds a higher clock on that shape, DESIGN 3.9 --
+// and the data-gradient chain (mlp_dgrad_x3_kernel) v_mfma_f32_32x32x16_bf16, the form everything was first written in
+// (mlp_bf16x3_kernel: kept as an A/B build of the forward, -DX3_FWD_32X32).  The description that follows is the 32x32x16
+// form; the 16x16x32 section says what changes.
+//
 // Shape: the fp32 kernel's chain (mlp_chain.h: one wave = 32 points x 256 features, all 8 accumulator blocks Y of a
 // layer live, the next layer's input X made from Y just in time while output block 0 accumulates), with X held as
 // three bf16 B-fragment sets (192 registers) instead of fp32 (128), and the weight stream in 3-KiB steps
