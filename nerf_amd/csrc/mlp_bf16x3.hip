@@ -191,6 +191,23 @@ __device__ __forceinline__ void xr_start(XRingS& st, const char* stream_base, ch
 
 // Input op of a hidden-type layer: X[kb] (three-term B fragments) from Y[kb] of the previous layer, in eight slices of
 // one register pair each (15 VALU instructions per slice behind OpInBase's activation).
+// backward layers whose output did not feed alpha_linear (all but h7): kOpBwd without the alpha term -- no head-row read
+// from LDS (and its wait) in every third MFMA gap, no multiply-add by a d sigma that is zero.  Same bits (the term was
+// fma(w, 0, y)); chain 5.52 -> 5.36 ms per step on one box.  The h7 layer is peeled out of the layer loop: as an if / else
+// of two instantiations inside the loop the kernel needed 300 B of scratch per lane and ran 24 % slower.
+#ifdef X3_BWD_ALPHA_ALWAYS   // (A/B switch)
+constexpr int kOpBwdPlain = kOpBwd;
+#else
+constexpr int kOpBwdPlain = 3;
+#endif
+// ... and the two layers whose input has no activation in front of it (views^T: dYv is masked where it is made; feature^T:
+// no relu between feature_linear and views_linears): no sign word either
+#ifdef X3_BWD_MASK_ALWAYS    // (A/B switch)
+constexpr int kOpBwdOpen = kOpBwdPlain;
+#else
+constexpr int kOpBwdOpen = 4;
+#endif
+constexpr bool op_is_bwd(int mode) { return mode == kOpBwd || mode == kOpBwdPlain || mode == kOpBwdOpen; }
 struct OpIn : OpInBase {
     // the same pair in three sub-slices of ~5 VALU instructions, one per MFMA gap (15 in one gap hold the wave's
     // in-order MFMA issue for 60 cycles: the matrix pipe runs dry behind them)
@@ -199,7 +216,13 @@ struct OpIn : OpInBase {
     SplitSel k;   // the residuals by v_dot2c_f32_bf16 (split3.h): 3 + 3 + 3 instructions per pair behind the activation
     template <int MODE, class YT>
     __device__ __forceinline__ void input(const YT& y, int blk, int q, float& a, float& b) {
-        if (MODE == kOpBwd) {
+        if (MODE == kOpBwdOpen && kOpBwdOpen != kOpBwdPlain) {
+            a = y[2 * q], b = y[2 * q + 1];
+        } else if (MODE == kOpBwdPlain && kOpBwdPlain != kOpBwd) {
+            const int word = int(m[blk >> 1]), at = 16 * (blk & 1) + 2 * q;
+            a = __int_as_float(__float_as_int(y[2 * q]) & __builtin_amdgcn_sbfe(word, at, 1));
+            b = __int_as_float(__float_as_int(y[2 * q + 1]) & __builtin_amdgcn_sbfe(word, at + 1, 1));
+        } else if (MODE == kOpBwd) {
             const float2 w = *reinterpret_cast<const float2*>(aw + blk * 32 + 2 * q);
             const int word = int(m[blk >> 1]), at = 16 * (blk & 1) + 2 * q;   // (split_stream.h: OpInBase::input)
             a = __int_as_float(__float_as_int(fmaf(w.x, dsig, y[2 * q])) & __builtin_amdgcn_sbfe(word, at, 1));
@@ -216,7 +239,7 @@ struct OpIn : OpInBase {
             input<MODE>(y, blk, q, sa, sb);
             p0 = pk_bf16(sa, sb);
             x[q / 4][0][q % 4] = p0;
-        } else if (MODE == kOpBwd) {   // the backward chain keeps the shift / mask / subtract form: measured 1.5 % faster there
+        } else if (op_is_bwd(MODE)) {   // the backward chain keeps the shift / mask / subtract form: measured 1.5 % faster there
             if (phase == 1) {          // (tools/debug/lib_ab_prof.sh, one box: chain 5.70 against 5.78 ms per step)
                 ra = __fsub_rn(sa, bf_lo(p0)), rb = __fsub_rn(sb, bf_hi(p0));
                 p1 = pk_bf16(ra, rb);
@@ -237,7 +260,7 @@ struct OpIn : OpInBase {
         float a, b;
         input<MODE>(y, blk, q, a, b);
         unsigned p0, p1, p2;
-        if (MODE == kOpBwd) split_pair(a, b, p0, p1, p2);
+        if (op_is_bwd(MODE)) split_pair(a, b, p0, p1, p2);
         else split_pair_dot2(k, a, b, p0, p1, p2);
         x[q / 4][0][q % 4] = p0, x[q / 4][1][q % 4] = p1, x[q / 4][2][q % 4] = p2;
     }
@@ -304,7 +327,7 @@ __device__ __forceinline__ void x3_hidden_layer(XRing& st, int lane, const float
                                                 const u32x4 (*post)[2][3], f32x16* Y, f32x16& Z, OpIn& op) {
     constexpr int NKB = NHID + NPOST;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto bias = [&](int ob) { return MODE == kOpBwd ? zero16 : *reinterpret_cast<const f32x16*>(bias_h + ob * 32); };
+    auto bias = [&](int ob) { return op_is_bwd(MODE) ? zero16 : *reinterpret_cast<const f32x16*>(bias_h + ob * 32); };
     static_assert((NOB * NKB * 2) % kXChunkSteps == 0, "layer must be a whole number of chunks");
 #pragma unroll
     for (int q = 0; q < 8; ++q) op.template pair<MODE>(Y[0], X[0], 0, q);
@@ -798,10 +821,11 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_x3_kernel(const float* __res
         OpIn op{op_in(kActNone, aw, drow + kDyV * 32), 0.f, 0.f, 0.f, 0.f, 0u, 0u, sel};
 #pragma unroll
         for (int w = 0; w < 4; ++w) op.m[w] = ~0u;
-        x3_hidden_layer<8, 0, kOpBwd, 4>(st, lane, nullptr, X, nullptr, Y, Z, op);
+        x3_hidden_layer<8, 0, kOpBwdOpen, 4>(st, lane, nullptr, X, nullptr, Y, Z, op);
         // li = 0: d h7 = W_feature^T . d feature (no activation between feature_linear and views_linears: all-ones mask,
         // stored as the dY rows of feature_linear); li = 1 .. 7: layer l = 8 - li, dY_l = relu'(h_l) * d h_l (+ the
         // alpha_linear term for h7), d h_{l-1} = W_l^T . dY_l.  One body, run-time loop.
+#ifdef X3_BWD_ALPHA_ALWAYS
         for (int li = 0; li <= 7; ++li) {
             const int l = 8 - li;
             op.save = drow + (li == 0 ? kDyFeat : l * 256) * 32;
@@ -810,6 +834,22 @@ __global__ __launch_bounds__(256, 1) void mlp_dgrad_x3_kernel(const float* __res
             op.dsig = li == 1 ? g.w : 0.f;                       // h7 also feeds alpha_linear
             x3_hidden_layer<8, 0, kOpBwd>(st, lane, nullptr, X, nullptr, Y, Z, op);
         }
+#else
+        op.save = drow + kDyFeat * 32;                           // li = 0: feature^T
+        x3_hidden_layer<8, 0, kOpBwdOpen>(st, lane, nullptr, X, nullptr, Y, Z, op);
+        op.save = drow + 7 * 256 * 32;                           // li = 1: h7 also feeds alpha_linear
+#pragma unroll
+        for (int w = 0; w < 4; ++w) op.m[w] = mrow[(7 * 4 + w) * 64];
+        op.dsig = g.w;
+        x3_hidden_layer<8, 0, kOpBwd>(st, lane, nullptr, X, nullptr, Y, Z, op);
+        op.dsig = 0.f;
+        for (int l = 6; l >= 1; --l) {
+            op.save = drow + l * 256 * 32;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) op.m[w] = mrow[(l * 4 + w) * 64];
+            x3_hidden_layer<8, 0, kOpBwdPlain>(st, lane, nullptr, X, nullptr, Y, Z, op);
+        }
+#endif
         {   // dY_0 = relu'(h_0) * d h_0 (the encoding needs no gradient: the chain ends here)
             OpBwdMask last;
             last.dst = drow;
